@@ -1,0 +1,348 @@
+// attn.hip -- fp32 self-attention forward / backward for the PC-ViT block on
+// v_mfma_f32_16x16x4_f32 (gfx950).  Replaces eqx.nn.MultiheadAttention as wrapped by
+// pxnn.MultiHeadAttention (/root/reference/pcx/nn/_layer.py:359-402): no biases, no mask,
+// no dropout, logits = (q/sqrt(d)) k^T, softmax over keys, per-head column blocks.
+//
+// One workgroup (4 waves) per (image, head, 64 "own" rows); each wave owns 16 rows held as MFMA
+// B-operand fragments in registers, and the workgroup streams the other side through LDS in
+// 64-row chunks (one chunk = the whole sequence at N = 64, so K/V are LDS-resident there).
+//   forward : own = queries, stream keys/values, online softmax, writes O and base-2 LSE
+//   bwd-q   : own = queries (+dO), stream K,V : S, dP recomputed, dQ accumulated; also delta=rowsum(dO*O)
+//   bwd-kv  : own = keys (+V),   stream Q,dO : S, dP recomputed, dK, dV accumulated
+// Nothing is summed across workgroups, so the results are deterministic (no atomics).
+//
+// MFMA operand maps used throughout (lane l, c = l & 15, grp = l >> 4):
+//   score   tile  D[i][j] = sum_dd X[i][dd] Y[j][dd] : A = X[i=c][4s+grp], B = Y[j=c][4s+grp];
+//                 lane holds D[i = 4grp+reg][j = c]  (the own row j stays on the lane)
+//   accum   tile  D[cc][j] += sum_i Z[i][cc] W[i][j] : A = Z[i = 4grp+reg][cc = c], B = score regs
+#include "common.h"
+
+#define CH 64  // streamed rows per chunk
+
+template <int DH>
+struct AttnSmem {
+  static constexpr int LD = DH + 4;
+  float s1[CH * LD];
+  float s2[CH * LD];
+  float rowc[2 * CH];  // per streamed row constants (lse2, delta) for bwd-kv
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// stage rows [r0, r0+CH) x [0,DH) of a [*, ld] matrix (column offset already applied) into LDS
+template <int DH>
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld, int r0, int nrows) {
+  constexpr int LD = DH + 4;
+  constexpr int V = DH / 4;  // float4 per row
+  for (int f = threadIdx.x; f < CH * V; f += 256) {
+    int row = f / V, c4 = f % V;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < nrows) v = *reinterpret_cast<const float4*>(src + (long long)(r0 + row) * ld + 4 * c4);
+    *reinterpret_cast<float4*>(&dst[row * LD + 4 * c4]) = v;
+  }
+}
+
+// own-row fragment: f[s] = X[row][4s+grp]
+template <int DH>
+__device__ __forceinline__ void load_frag(float* f, const float* src, int ld, int row, int nrows, int grp) {
+#pragma unroll
+  for (int s = 0; s < DH / 4; ++s) f[s] = (row < nrows) ? src[(long long)row * ld + 4 * s + grp] : 0.f;
+}
+
+// S[tt] (tt = 0..3) = streamed rows 16tt..16tt+15 (from LDS) x own fragment
+template <int DH>
+__device__ __forceinline__ void score_tiles(f32x4* S, const float* lds, const float* frag, int c, int grp) {
+  constexpr int LD = DH + 4;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) S[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < DH / 4; ++s) {
+    float b = frag[s];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) S[tt] = mfma16(lds[(16 * tt + c) * LD + 4 * s + grp], b, S[tt]);
+  }
+}
+
+// acc[ct] (ct = 0..DH/16-1) += sum over the 64 streamed rows of Z[row][16ct + c] * Pv[row][own]
+template <int DH>
+__device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const f32x4* Pv, int c, int grp) {
+  constexpr int LD = DH + 4;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      float b = Pv[tt][reg];
+      const float* zr = &lds[(16 * tt + 4 * grp + reg) * LD + c];
+#pragma unroll
+      for (int ct = 0; ct < DH / 16; ++ct) acc[ct] = mfma16(zr[16 * ct], b, acc[ct]);
+    }
+}
+
+__device__ __forceinline__ float grp_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float grp_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
+                                                       float* __restrict__ lse2, int N, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
+  const int img = blockIdx.z, h = blockIdx.y;
+  const int ld = 3 * D;
+  const float* base = qkv + (long long)img * N * ld;
+  const float* Q = base + h * DH;
+  const float* K = base + D + h * DH;
+  const float* V = base + 2 * D + h * DH;
+  const int qrow = blockIdx.x * 64 + 16 * w + c;
+  const float sc = rsqrtf((float)DH) * CORA_LOG2E;  // base-2 logits
+
+  float qf[DH / 4];
+  load_frag<DH>(qf, Q, ld, qrow, N, grp);
+  f32x4 oacc[DH / 16];
+#pragma unroll
+  for (int ct = 0; ct < DH / 16; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+
+  for (int k0 = 0; k0 < N; k0 += CH) {
+    __syncthreads();
+    stage_rows<DH>(sm.s1, K, ld, k0, N);
+    stage_rows<DH>(sm.s2, V, ld, k0, N);
+    __syncthreads();
+    f32x4 S[4];
+    score_tiles<DH>(S, sm.s1, qf, c, grp);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int key = k0 + 16 * tt + 4 * grp + reg;
+        float s = (key < N) ? S[tt][reg] * sc : -INFINITY;
+        S[tt][reg] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = grp_max(mx);
+    float mnew = fmaxf(m, mx);               // finite: every chunk holds at least one valid key
+    float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    float ps = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float pv = __builtin_amdgcn_exp2f(S[tt][reg] - mnew);
+        S[tt][reg] = pv;
+        ps += pv;
+      }
+    ps = grp_sum(ps);
+    lsum = lsum * alpha + ps;
+    m = mnew;
+#pragma unroll
+    for (int ct = 0; ct < DH / 16; ++ct) oacc[ct] *= alpha;
+    accum_tiles<DH>(oacc, sm.s2, S, c, grp);
+  }
+  if (qrow < N) {
+    float inv = 1.0f / lsum;
+    float* orow = O + ((long long)img * N + qrow) * D + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < DH / 16; ++ct) {
+      float4 v = make_float4(oacc[ct][0] * inv, oacc[ct][1] * inv, oacc[ct][2] * inv, oacc[ct][3] * inv);
+      *reinterpret_cast<float4*>(orow + 16 * ct + 4 * grp) = v;
+    }
+    if (grp == 0) lse2[((long long)img * N + qrow) * H + h] = m + __builtin_amdgcn_logf(lsum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+                                                         const float* __restrict__ lse2, const float* __restrict__ dO,
+                                                         float* __restrict__ delta, float* __restrict__ dqkv,
+                                                         int N, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
+  const int img = blockIdx.z, h = blockIdx.y;
+  const int ld = 3 * D;
+  const float* base = qkv + (long long)img * N * ld;
+  const float* Q = base + h * DH;
+  const float* K = base + D + h * DH;
+  const float* V = base + 2 * D + h * DH;
+  const float* dOp = dO + (long long)img * N * D + h * DH;
+  const float* Op = O + (long long)img * N * D + h * DH;
+  const int qrow = blockIdx.x * 64 + 16 * w + c;
+  const float scale = rsqrtf((float)DH);
+  const float sc = scale * CORA_LOG2E;
+
+  float qf[DH / 4], dof[DH / 4];
+  load_frag<DH>(qf, Q, ld, qrow, N, grp);
+  load_frag<DH>(dof, dOp, D, qrow, N, grp);
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < DH / 4; ++s) {
+    float ov = (qrow < N) ? Op[(long long)qrow * D + 4 * s + grp] : 0.f;
+    dl += dof[s] * ov;
+  }
+  dl = grp_sum(dl);
+  const float l2 = (qrow < N) ? lse2[((long long)img * N + qrow) * H + h] : 0.f;
+  if (qrow < N && grp == 0) delta[((long long)img * N + qrow) * H + h] = dl;
+
+  f32x4 acc[DH / 16];
+#pragma unroll
+  for (int ct = 0; ct < DH / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < N; k0 += CH) {
+    __syncthreads();
+    stage_rows<DH>(sm.s1, K, ld, k0, N);
+    stage_rows<DH>(sm.s2, V, ld, k0, N);
+    __syncthreads();
+    f32x4 S[4], dP[4];
+    score_tiles<DH>(S, sm.s1, qf, c, grp);
+    score_tiles<DH>(dP, sm.s2, dof, c, grp);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int key = k0 + 16 * tt + 4 * grp + reg;
+        float pv = (key < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - l2) : 0.f;
+        S[tt][reg] = pv * (dP[tt][reg] - dl);  // dS
+      }
+    accum_tiles<DH>(acc, sm.s1, S, c, grp);  // dQ^T += K^T dS^T
+  }
+  if (qrow < N) {
+    float* drow = dqkv + ((long long)img * N + qrow) * ld + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < DH / 16; ++ct) {
+      float4 v = make_float4(acc[ct][0] * scale, acc[ct][1] * scale, acc[ct][2] * scale, acc[ct][3] * scale);
+      *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+                                                          const float* __restrict__ dO, const float* __restrict__ delta,
+                                                          float* __restrict__ dqkv, int N, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
+  const int img = blockIdx.z, h = blockIdx.y;
+  const int ld = 3 * D;
+  const float* base = qkv + (long long)img * N * ld;
+  const float* Q = base + h * DH;
+  const float* K = base + D + h * DH;
+  const float* V = base + 2 * D + h * DH;
+  const float* dOp = dO + (long long)img * N * D + h * DH;
+  const int krow = blockIdx.x * 64 + 16 * w + c;
+  const float scale = rsqrtf((float)DH);
+  const float sc = scale * CORA_LOG2E;
+
+  float kf[DH / 4], vf[DH / 4];
+  load_frag<DH>(kf, K, ld, krow, N, grp);
+  load_frag<DH>(vf, V, ld, krow, N, grp);
+  f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+  for (int ct = 0; ct < DH / 16; ++ct) {
+    dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int q0 = 0; q0 < N; q0 += CH) {
+    __syncthreads();
+    stage_rows<DH>(sm.s1, Q, ld, q0, N);
+    stage_rows<DH>(sm.s2, dOp, D, q0, N);
+    if (threadIdx.x < CH) {
+      int q = q0 + threadIdx.x;
+      long long ri = ((long long)img * N + q) * H + h;
+      sm.rowc[threadIdx.x] = (q < N) ? lse2[ri] : 0.f;
+      sm.rowc[CH + threadIdx.x] = (q < N) ? delta[ri] : 0.f;
+    }
+    __syncthreads();
+    f32x4 S[4], dP[4];
+    score_tiles<DH>(S, sm.s1, kf, c, grp);   // S[q][key]
+    score_tiles<DH>(dP, sm.s2, vf, c, grp);  // dP[q][key] = dO[q] . V[key]
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int ql = 16 * tt + 4 * grp + reg;
+        float pv = (q0 + ql < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - sm.rowc[ql]) : 0.f;
+        S[tt][reg] = pv;                                        // P
+        dP[tt][reg] = pv * (dP[tt][reg] - sm.rowc[CH + ql]);    // dS
+      }
+    accum_tiles<DH>(dv, sm.s2, S, c, grp);   // dV^T += dO^T P
+    accum_tiles<DH>(dk, sm.s1, dP, c, grp);  // dK^T += Q^T dS
+  }
+  if (krow < N) {
+    float* drow = dqkv + ((long long)img * N + krow) * ld + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < DH / 16; ++ct) {
+      float4 a = make_float4(dk[ct][0] * scale, dk[ct][1] * scale, dk[ct][2] * scale, dk[ct][3] * scale);
+      float4 b = make_float4(dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]);
+      *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) = a;
+      *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
+  size_t sm = sizeof(AttnSmem<DH>);
+  static bool attr_set = false;
+  if (!attr_set && sm > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attr_set = true;
+  }
+  dim3 grid((N + 63) / 64, H, nimg);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, N, H, D);
+  return 0;
+}
+template <int DH>
+static int run_bwd(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
+                   float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+  size_t sm = sizeof(AttnSmem<DH>);
+  static bool attr_set = false;
+  if (!attr_set && sm > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attr_set = true;
+  }
+  dim3 grid((N + 63) / 64, H, nimg);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, dO, delta, dqkv, N, H, D);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, dim3(256), sm, st, qkv, lse2, dO, delta, dqkv, N, H, D);
+  return 0;
+}
+
+#define DISPATCH_DH(dh, CALL)        \
+  switch (dh) {                      \
+    case 16: return CALL(16);        \
+    case 32: return CALL(32);        \
+    case 48: return CALL(48);        \
+    case 64: return CALL(64);        \
+    case 96: return CALL(96);        \
+    case 128: return CALL(128);      \
+    default: return -1;              \
+  }
+
+int launch_attn_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
+#define CALL(X) run_fwd<X>(qkv, O, lse2, nimg, N, H, D, st)
+  DISPATCH_DH(D / H, CALL)
+#undef CALL
+}
+int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
+                    float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+#define CALL(X) run_bwd<X>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st)
+  DISPATCH_DH(D / H, CALL)
+#undef CALL
+}

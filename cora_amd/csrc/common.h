@@ -1,0 +1,126 @@
+// common.h -- shared device helpers and kernel parameter blocks (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CORA_LOG2E 1.4426950408889634f
+
+// ---- tanh-GELU (jax.nn.gelu approximate=True, pcx/nn/_layer.py:439) -------------------------
+__device__ __forceinline__ float cora_tanhf(float x) {
+  // tanh(x) = 1 - 2/(1+exp(2x)); exp2-based, saturates cleanly for |x| large.
+  float e = __builtin_amdgcn_exp2f(x * (2.0f * CORA_LOG2E));
+  return 1.0f - 2.0f / (1.0f + e);
+}
+__device__ __forceinline__ float cora_gelu(float a) {
+  const float c0 = 0.7978845608028654f, c1 = 0.044715f;
+  float t = cora_tanhf(c0 * (a + c1 * a * a * a));
+  return 0.5f * a * (1.0f + t);
+}
+__device__ __forceinline__ float cora_gelu_grad(float a) {
+  const float c0 = 0.7978845608028654f, c1 = 0.044715f;
+  float t = cora_tanhf(c0 * (a + c1 * a * a * a));
+  return 0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * c0 * (1.0f + 3.0f * c1 * a * a);
+}
+
+// ---- wave (64 lanes) and block reductions ------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in thread 0.  `sh` = 4 doubles of LDS.
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+  v = wave_sum_d(v);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  return r;
+}
+
+// ---- GEMM parameter block ----------------------------------------------------------------------
+enum GemmOut {
+  OUT_STORE = 0,     // C = v
+  OUT_ERR = 1,       // e = tgt - v ; C = e ; red += 1/2 e^2 + l1|tgt| + l2 tgt^2
+  OUT_GELUGRAD = 2,  // C = v * gelu'(aux)
+  OUT_GRAD = 3,      // g = alpha2 * (own + l1 sign(hreg) + 2 l2 hreg - v) ; C = g ; red += g^2
+  OUT_ATOMIC = 4     // atomicAdd(C, v)
+};
+
+struct GemmP {
+  const float* A;   // operand rows x K   (K-inner)  or K x rows (K-outer, "TN")
+  const float* Bw;  // operand cols x K   (K-inner, "NT": weight [out,in]) or K x cols (K-outer)
+  float* C;
+  int R, O, K;           // rows, cols, reduction length (per group)
+  int lda, ldb, ldc;
+  long long sA, sB, sC;  // per-group element strides
+  int groups, splitk;
+  int a_gelu;            // apply tanh-GELU to A while staging (MLP2 reads the pre-activation)
+  int b_gelu;            // same for the B operand (weight-gradient of linear2)
+  float alpha;           // v = alpha * acc (+ bias + pos + res1 + res2)
+  const float* bias; long long sBias;
+  const float* pos; int posN;
+  const float* res1; const float* res2;   // same shape / strides as C
+  int mode;
+  const float* tgt;      // OUT_ERR target (h of the predicted vode); OUT_GRAD: own error (may be null)
+  const float* hreg;     // OUT_GRAD: h for the regulariser terms (may be null)
+  const float* aux;      // OUT_GELUGRAD: pre-activation a   (ld = ldc)
+  float alpha2, l1, l2;
+  double* red; int red_stride;   // red[g * red_stride] accumulates energy / sum of squares
+};
+
+void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
+
+// ---- attention ------------------------------------------------------------------------------------
+// qkv: [rows, 3D] (q | k | v, head h = columns h*dh..), O: [rows, D], lse2: [rows, H] (base-2 LSE)
+int launch_attn_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D,
+                    hipStream_t st);
+// dqkv: [rows, 3D]; delta: [rows, H] scratch
+int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const float* dO,
+                    float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
+
+// ---- row-wise / element-wise ---------------------------------------------------------------------
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long long sParam,
+                  float* xn, float* stats, int rows_per_group, int groups, int D, hipStream_t st);
+// mode 0 (LN2): out = r + LNbwd(dxn)
+// mode 1 (LN1): dxt = r + dy + LNbwd(dxn);  out = gscale[g]*(own + l1 sign(x) + 2 l2 x - dxt);
+//               red[(g) * red_stride] += out^2
+struct LnBwdP {
+  const float* dxn; const float* x; const float* stats; const float* gamma; long long sParam;
+  const float* r; const float* dy; const float* own;
+  float* out; int rows_per_group, groups, D, mode;
+  const float* gscale; float l1, l2; double* red; int red_stride;
+};
+int launch_ln_bwd(const LnBwdP& p, hipStream_t st);
+
+void launch_patchify(const float* img, float* xp, int B, int F, int C, int Himg, int Wimg, int p,
+                     int to_image, hipStream_t st);
+// vode update: scale/clip from sumsq, m = g*mult + mu*m, h -= eta*m
+struct UpdateP {
+  float* h; float* m; const float* g; long long n0, nl; int nlayers;  // layer 0 has n0 floats, others nl
+  const double* sumsq;  // [nlayers] sums of squares of the (scaled) grads of this step
+  float clip, mu; const float* eta; int t;
+  int use_grad_norm; float grad_norm_target;
+};
+void launch_update(const UpdateP& p, hipStream_t st);
+// column sums: out[g*sOut + c] += alpha * sum_rows a[row, c] * (b ? b'[row, c] : 1), where
+// b' = b, or (b - mean[row]) * rstd[row] when stats ([rows,2]) is given
+void launch_colsum(const float* a, const float* b, const float* stats, float* out, long long sOut,
+                   int rows_per_group, int groups, int cols, float alpha, hipStream_t st);
+void launch_sumsq(const float* a, long long n, float scale, double* out, hipStream_t st);
+struct AdamP {
+  float* w; const float* g; float* mu; float* nu; long long n;
+  const double* sumsq; float gscale, clip, lr, b1, b2, eps, wd; float bc1, bc2;
+};
+void launch_adamw(const AdamP& p, hipStream_t st);
+// red[0] += sum (clip01(a)-clip01(b))^2
+void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st);

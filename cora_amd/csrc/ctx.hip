@@ -1,0 +1,871 @@
+// ctx.hip -- context, memory layout, step orchestration, hipGraph capture and the C ABI
+// (include/cora_hip.h) of libcora_hip.so.  Host code only; kernels live in gemm/attn/rowwise.hip.
+//
+// Step order follows train_on_batch, /root/reference/src/decoder_transformer.py:392-499 (mode 2).
+#include "../../include/cora_hip.h"
+#include "common.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_err;
+
+enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_COUNT };
+const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd",
+                                   "ln_fwd", "ln_bwd", "vode_update", "other"};
+
+struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+
+}  // namespace
+
+struct cora_ctx {
+  cora_config cfg;
+  int device = 0;
+  hipStream_t st = nullptr;
+  std::string err;
+
+  // dims
+  int N, P, D, H, M, L, B;
+  long long BN;       // B*N rows per layer
+  long long n0, nl;   // floats in vode 0 / vodes 1..L+1
+  long long nV;       // n0 + (L+1)*nl
+  int Tmax;
+
+  // weight arena + optimizer
+  size_t nW = 0;
+  float *W = nullptr, *dW = nullptr, *amu = nullptr, *anu = nullptr;
+  bool dW_owned = true;
+  int64_t adam_count = 0;
+  size_t oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, oWp, obp, oWout, obout;
+  float* pos = nullptr;
+
+  // vodes
+  float *Hs = nullptr, *Ms = nullptr, *Gs = nullptr, *Es = nullptr;  // Es: e_1..e_{L+1} then e_img
+  float* xp = nullptr;     // target, patch layout [BN, P]
+  float* ximg = nullptr;   // image staging [B, F*C*H*W]
+  long long nImg;
+
+  // block scratch for Gmax groups
+  int Gmax;
+  float *xn1, *st1, *qkv, *att, *lse, *y, *xn2, *st2, *a;
+  float *da, *dzn, *dy, *dO, *delta, *dqkv, *dxn;
+  float *ua, *ub, *z;
+  float* gscale = nullptr;   // [L] layer scale of the vode each block reads
+  float* eta_dev = nullptr;  // [Tmax]
+  double* energies = nullptr;  // [(Tmax+2), L+3]
+  double* sumsq = nullptr;     // [(Tmax+2), L+2]
+  double* scal = nullptr;      // [0]=w-grad sumsq, [1]=mse sum
+  float scale_l[64];
+
+  std::map<int, hipGraphExec_t> graphs;
+  bool use_graph = true;
+  bool warmed = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_T = 0;
+
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+#define HCHECK(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      char buf_[512];                                                                     \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+               __FILE__, __LINE__);                                                       \
+      c->err = buf_;                                                                      \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+#define FAIL(code, msg) \
+  do { c->err = (msg); return (code); } while (0)
+
+struct KScope {
+  cora_ctx* c; bool on;
+  KScope(cora_ctx* c_, int kind, double flops, double bytes) : c(c_), on(c_->prof) {
+    if (!on) return;
+    ProfRec r; r.kind = kind; r.flops = flops; r.bytes = bytes;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, c->st);
+    c->recs.push_back(r);
+  }
+  ~KScope() { if (on) hipEventRecord(c->recs.back().e1, c->st); }
+};
+
+int dalloc(cora_ctx* c, float** p, long long n) {
+  void* v = nullptr;
+  if (n < 1) n = 1;
+  HCHECK(hipMalloc(&v, (size_t)n * sizeof(float)));
+  HCHECK(hipMemsetAsync(v, 0, (size_t)n * sizeof(float), c->st));
+  c->allocs.push_back(v);
+  *p = (float*)v;
+  return 0;
+}
+
+float* vode_ptr(cora_ctx* c, float* base, int l) { return l == 0 ? base : base + c->n0 + (long long)(l - 1) * c->nl; }
+float* err_ptr(cora_ctx* c, int l) { return c->Es + (long long)(l - 1) * c->nl; }  // l = 1..L+1 ; L+2 = e_img
+
+GemmP gemm_base(cora_ctx* c) {
+  GemmP p;
+  memset(&p, 0, sizeof p);
+  p.groups = 1; p.splitk = 1; p.alpha = 1.f; p.alpha2 = 1.f; p.mode = OUT_STORE;
+  p.l1 = 0.f; p.l2 = 0.f; p.red_stride = 1;
+  (void)c;
+  return p;
+}
+
+void run_gemm(cora_ctx* c, const GemmP& p, bool ako, bool bko) {
+  int kind = ako ? K_GEMM_TN : (bko ? K_GEMM_NN : K_GEMM_NT);
+  double fl = 2.0 * p.R * (double)p.O * p.K * p.groups;
+  double by = 4.0 * p.groups * ((double)p.R * p.K + (double)p.O * p.K + (double)p.R * p.O);
+  KScope s(c, kind, fl, by);
+  launch_gemm(p, ako, bko, c->st);
+}
+
+// patch projection: u_1 = h_0 Wp^T + bp + pos   (src/decoder_transformer.py:222-228)
+void patch_proj(cora_ctx* c, const float* h0, float* out, int mode, const float* tgt, double* red) {
+  GemmP p = gemm_base(c);
+  p.A = h0; p.Bw = c->W + c->oWp; p.C = out;
+  p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->P; p.ldc = c->D;
+  p.bias = c->W + c->obp; p.pos = c->pos; p.posN = c->N;
+  p.mode = mode; p.tgt = tgt; p.red = red; p.l1 = c->cfg.l1; p.l2 = c->cfg.l2;
+  run_gemm(c, p, false, false);
+}
+
+// output projection: z = h_{L+1} Wout^T + bout (patch layout; unpatchify is a permutation, :244-250)
+void out_proj(cora_ctx* c, const float* hin, float* out, int mode, const float* tgt, double* red) {
+  GemmP p = gemm_base(c);
+  p.A = hin; p.Bw = c->W + c->oWout; p.C = out;
+  p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->D; p.ldc = c->P;
+  p.bias = c->W + c->obout;
+  p.mode = mode; p.tgt = tgt; p.red = red;  // sensory vode: plain se_energy, no regulariser
+  run_gemm(c, p, false, false);
+}
+
+// Forward of G transformer blocks (blocks b0..b0+G-1), block g reading xin + g*BN*D:
+//   u = 2x + MHA(LN1 x) + MLP(LN2(x + MHA(LN1 x)))   (pcx/nn/_layer.py:428-447 + decoder :238)
+// mode OUT_ERR : C = tgt - u written to `out` (errors), energies accumulated at red[g]
+// mode OUT_STORE: C = u
+int block_forward(cora_ctx* c, int G, int b0, const float* xin, float* out, int mode, const float* tgt, double* red) {
+  const int D = c->D, M = c->M, H = c->H;
+  const int R = (int)c->BN;
+  const long long rows = (long long)G * R;
+  {
+    KScope s(c, K_LN_FWD, 0, 8.0 * rows * D);
+    if (launch_ln_fwd(xin, c->W + c->oLn1g + (size_t)b0 * D, c->W + c->oLn1b + (size_t)b0 * D, D, c->xn1, c->st1, R, G, D, c->st))
+      FAIL(-3, "layer norm: hidden size not supported");
+  }
+  GemmP p = gemm_base(c);
+  p.groups = G;
+  // QKV
+  p.A = c->xn1; p.Bw = c->W + c->oWqkv + (size_t)b0 * 3 * D * D; p.C = c->qkv;
+  p.R = R; p.O = 3 * D; p.K = D; p.lda = D; p.ldb = D; p.ldc = 3 * D;
+  p.sA = (long long)R * D; p.sB = 3LL * D * D; p.sC = (long long)R * 3 * D;
+  run_gemm(c, p, false, false);
+  {
+    double fl = 4.0 * G * c->B * (double)c->N * c->N * D;
+    KScope s(c, K_ATTN_FWD, fl, 4.0 * rows * 4 * D);
+    if (launch_attn_fwd(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention: head dim not supported (need 16,32,48,64,96,128)");
+  }
+  // y = x + att Wo^T
+  p = gemm_base(c); p.groups = G;
+  p.A = c->att; p.Bw = c->W + c->oWo + (size_t)b0 * D * D; p.C = c->y;
+  p.R = R; p.O = D; p.K = D; p.lda = D; p.ldb = D; p.ldc = D;
+  p.sA = (long long)R * D; p.sB = (long long)D * D; p.sC = (long long)R * D;
+  p.res1 = xin;
+  run_gemm(c, p, false, false);
+  {
+    KScope s(c, K_LN_FWD, 0, 8.0 * rows * D);
+    launch_ln_fwd(c->y, c->W + c->oLn2g + (size_t)b0 * D, c->W + c->oLn2b + (size_t)b0 * D, D, c->xn2, c->st2, R, G, D, c->st);
+  }
+  // a = LN2(y) W1^T + b1
+  p = gemm_base(c); p.groups = G;
+  p.A = c->xn2; p.Bw = c->W + c->oW1 + (size_t)b0 * M * D; p.C = c->a;
+  p.R = R; p.O = M; p.K = D; p.lda = D; p.ldb = D; p.ldc = M;
+  p.sA = (long long)R * D; p.sB = (long long)M * D; p.sC = (long long)R * M;
+  p.bias = c->W + c->ob1 + (size_t)b0 * M; p.sBias = M;
+  run_gemm(c, p, false, false);
+  // u = x + y + gelu(a) W2^T + b2
+  p = gemm_base(c); p.groups = G;
+  p.A = c->a; p.a_gelu = 1; p.Bw = c->W + c->oW2 + (size_t)b0 * D * M; p.C = out;
+  p.R = R; p.O = D; p.K = M; p.lda = M; p.ldb = M; p.ldc = D;
+  p.sA = (long long)R * M; p.sB = (long long)D * M; p.sC = (long long)R * D;
+  p.bias = c->W + c->ob2 + (size_t)b0 * D; p.sBias = D;
+  p.res1 = xin; p.res2 = c->y;
+  p.mode = mode; p.tgt = tgt; p.red = red; p.red_stride = 1; p.l1 = c->cfg.l1; p.l2 = c->cfg.l2;
+  run_gemm(c, p, false, false);
+  return 0;
+}
+
+// Hand-derived VJP of G blocks with cotangent r (the next vode's error):
+//   dy = r + LN2^T(W1^T(gelu'(a) * (W2^T r)));  dx = r + dy + LN1^T(MHA^T(dy))
+// and, when gout != null, the vode gradient g_l = scale_l (e_l + reg - dx) with its sum of squares.
+int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r, const float* own, float* gout, double* red) {
+  const int D = c->D, M = c->M, H = c->H;
+  const int R = (int)c->BN;
+  const long long rows = (long long)G * R;
+  GemmP p = gemm_base(c); p.groups = G;
+  // da = (r W2) * gelu'(a)
+  p.A = r; p.Bw = c->W + c->oW2 + (size_t)b0 * D * M; p.C = c->da;
+  p.R = R; p.O = M; p.K = D; p.lda = D; p.ldb = M; p.ldc = M;
+  p.sA = (long long)R * D; p.sB = (long long)D * M; p.sC = (long long)R * M;
+  p.mode = OUT_GELUGRAD; p.aux = c->a;
+  run_gemm(c, p, false, true);
+  // dzn = da W1
+  p = gemm_base(c); p.groups = G;
+  p.A = c->da; p.Bw = c->W + c->oW1 + (size_t)b0 * M * D; p.C = c->dzn;
+  p.R = R; p.O = D; p.K = M; p.lda = M; p.ldb = D; p.ldc = D;
+  p.sA = (long long)R * M; p.sB = (long long)M * D; p.sC = (long long)R * D;
+  run_gemm(c, p, false, true);
+  {
+    LnBwdP q; memset(&q, 0, sizeof q);
+    q.dxn = c->dzn; q.x = c->y; q.stats = c->st2; q.gamma = c->W + c->oLn2g + (size_t)b0 * D; q.sParam = D;
+    q.r = r; q.out = c->dy; q.rows_per_group = R; q.groups = G; q.D = D; q.mode = 0;
+    KScope s(c, K_LN_BWD, 0, 16.0 * rows * D);
+    if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: shape not supported (B*N % 4 != 0 or D too large)");
+  }
+  // dO = dy Wo
+  p = gemm_base(c); p.groups = G;
+  p.A = c->dy; p.Bw = c->W + c->oWo + (size_t)b0 * D * D; p.C = c->dO;
+  p.R = R; p.O = D; p.K = D; p.lda = D; p.ldb = D; p.ldc = D;
+  p.sA = (long long)R * D; p.sB = (long long)D * D; p.sC = (long long)R * D;
+  run_gemm(c, p, false, true);
+  {
+    double fl = 14.0 * G * c->B * (double)c->N * c->N * D;   // 7 products (S and dP are recomputed per side)
+    KScope s(c, K_ATTN_BWD, fl, 4.0 * rows * 9 * D);
+    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+  }
+  // dxn = dqkv Wqkv
+  p = gemm_base(c); p.groups = G;
+  p.A = c->dqkv; p.Bw = c->W + c->oWqkv + (size_t)b0 * 3 * D * D; p.C = c->dxn;
+  p.R = R; p.O = D; p.K = 3 * D; p.lda = 3 * D; p.ldb = D; p.ldc = D;
+  p.sA = (long long)R * 3 * D; p.sB = 3LL * D * D; p.sC = (long long)R * D;
+  run_gemm(c, p, false, true);
+  if (gout) {
+    LnBwdP q; memset(&q, 0, sizeof q);
+    q.dxn = c->dxn; q.x = xin; q.stats = c->st1; q.gamma = c->W + c->oLn1g + (size_t)b0 * D; q.sParam = D;
+    q.r = r; q.dy = c->dy; q.own = own; q.out = gout; q.rows_per_group = R; q.groups = G; q.D = D; q.mode = 1;
+    q.gscale = c->gscale + b0; q.l1 = c->cfg.l1; q.l2 = c->cfg.l2; q.red = red; q.red_stride = 1;
+    KScope s(c, K_LN_BWD, 0, 28.0 * rows * D);
+    if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: shape not supported");
+  }
+  return 0;
+}
+
+// energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
+int errors_pass(cora_ctx* c, int slot) {
+  const int L = c->L;
+  double* en = c->energies + (long long)slot * (L + 3);
+  patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
+  if (L > 0) {
+    int rc = block_forward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
+    if (rc) return rc;
+  }
+  out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
+  return 0;
+}
+
+// one inference step t: errors, dE/dh for every un-frozen vode, layer scaling, clip, momentum SGD
+int infer_step(cora_ctx* c, int t) {
+  const int L = c->L;
+  int rc = errors_pass(c, t);
+  if (rc) return rc;
+  double* ss = c->sumsq + (long long)t * (L + 2);
+  // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
+  GemmP p = gemm_base(c);
+  p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
+  p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
+  p.mode = OUT_GRAD; p.alpha2 = c->scale_l[0]; p.red = ss + 0;
+  run_gemm(c, p, false, true);
+  // vode L+1: g = e_{L+1} + reg - e_img Wout
+  p = gemm_base(c);
+  p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
+  p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
+  p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
+  p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + L + 1;
+  run_gemm(c, p, false, true);
+  if (L > 0) {
+    rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 1);
+    if (rc) return rc;
+  }
+  UpdateP u; memset(&u, 0, sizeof u);
+  u.h = c->Hs; u.m = c->Ms; u.g = c->Gs; u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
+  u.sumsq = ss; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
+  u.use_grad_norm = c->cfg.use_grad_norm; u.grad_norm_target = c->cfg.grad_norm_target;
+  {
+    KScope s(c, K_UPDATE, 0, 20.0 * c->nV);
+    launch_update(u, c->st);
+  }
+  return 0;
+}
+
+int enqueue_infer(cora_ctx* c, int T) {
+  const int L = c->L;
+  HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (size_t)T * (L + 3), c->st));
+  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (size_t)T * (L + 2), c->st));
+  HCHECK(hipMemsetAsync(c->Ms, 0, sizeof(float) * (size_t)c->nV, c->st));   // optim_h.init, :414
+  for (int t = 0; t < T; ++t) {
+    int rc = infer_step(c, t);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// status "forward" chain (rule 'h -> u', :167-168,175-176): u_1 from h_0, each block reads the
+// previous u.  If into_vodes, u_l is written into h_l (INIT rule 'h, u <- u').  Leaves z in c->z.
+int chain_forward(cora_ctx* c, bool into_vodes) {
+  const int L = c->L;
+  float* cur = into_vodes ? vode_ptr(c, c->Hs, 1) : c->ua;
+  patch_proj(c, vode_ptr(c, c->Hs, 0), cur, OUT_STORE, nullptr, nullptr);
+  for (int i = 0; i < L; ++i) {
+    float* nxt = into_vodes ? vode_ptr(c, c->Hs, i + 2) : (cur == c->ua ? c->ub : c->ua);
+    int rc = block_forward(c, 1, i, cur, nxt, OUT_STORE, nullptr, nullptr);
+    if (rc) return rc;
+    cur = nxt;
+  }
+  out_proj(c, cur, c->z, OUT_STORE, nullptr, nullptr);
+  return 0;
+}
+
+int upload_x(cora_ctx* c, const float* x, int on_device) {
+  if (!x) FAIL(-1, "x is NULL");
+  HCHECK(hipMemcpyAsync(c->ximg, x, sizeof(float) * (size_t)c->nImg, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
+  KScope s(c, K_OTHER, 0, 8.0 * c->nImg);
+  launch_patchify(c->ximg, c->xp, c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 0, c->st);
+  return 0;
+}
+
+int pick_splitk(long long tiles, int K) {
+  long long s = 1024 / (tiles > 0 ? tiles : 1);
+  long long kmax = K / 64;
+  if (s > kmax) s = kmax;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+// C[g] (+)= -A^T B  with A [rows, R], B [rows, O]  (weight gradient, summed over the rows)
+void wgrad_gemm(cora_ctx* c, int G, const float* A, int R, long long sA, const float* Bm, int O, long long sB,
+                float* C, long long sC, int b_gelu) {
+  GemmP p = gemm_base(c);
+  p.groups = G;
+  p.A = A; p.Bw = Bm; p.C = C;
+  p.R = R; p.O = O; p.K = (int)c->BN; p.lda = R; p.ldb = O; p.ldc = O;
+  p.sA = sA; p.sB = sB; p.sC = sC;
+  p.alpha = -1.f; p.mode = OUT_ATOMIC; p.b_gelu = b_gelu;
+  long long tiles = (long long)((R + 127) / 128) * ((O + 63) / 64) * G;
+  p.splitk = pick_splitk(tiles, p.K);
+  run_gemm(c, p, true, true);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* cora_last_error(const cora_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return -1; }
+  *out = nullptr;
+  auto bad = [&](const char* m) { g_create_err = m; return -1; };
+  if (cfg->dtype_mode != 0) return bad("dtype_mode: only 0 (fp32 MFMA) is implemented");
+  if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return bad("non-positive dimension");
+  if (cfg->D % cfg->H) return bad("hidden_size must be divisible by num_heads");
+  if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return bad("D, P and M must be multiples of 4 (16-byte rows)");
+  if (((long long)cfg->B * cfg->N) % 4) return bad("B*N must be a multiple of 4");
+  if (cfg->L + 3 > 64) return bad("too many blocks (L <= 61)");
+  if (cfg->P != cfg->patch * cfg->patch * cfg->C) return bad("P != patch*patch*C");
+  if (cfg->N != cfg->F * (cfg->Himg / cfg->patch) * (cfg->Wimg / cfg->patch)) return bad("N != F*(H/p)*(W/p)");
+  if (cfg->L > 0) {
+    int dh = cfg->D / cfg->H;
+    if (!(dh == 16 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return bad("head dim must be one of 16,32,48,64,96,128");
+    if (cfg->D > 768) return bad("hidden_size > 768 not supported by the LayerNorm kernels");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bad("no HIP device visible");
+  if (device < 0 || device >= ndev) return bad("device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+
+  cora_ctx* c = new cora_ctx();
+  c->cfg = *cfg; c->device = device;
+  c->N = cfg->N; c->P = cfg->P; c->D = cfg->D; c->H = cfg->H; c->M = cfg->M; c->L = cfg->L; c->B = cfg->B;
+  c->BN = (long long)c->B * c->N;
+  c->n0 = c->BN * c->P; c->nl = c->BN * c->D; c->nV = c->n0 + (long long)(c->L + 1) * c->nl;
+  c->Tmax = cfg->max_T > 0 ? cfg->max_T : 64;
+  c->nImg = (long long)c->B * cfg->F * cfg->C * cfg->Himg * cfg->Wimg;
+  c->use_graph = getenv("CORA_NO_GRAPH") == nullptr;
+  auto fail = [&](int rc) { g_create_err = c->err; cora_destroy(c); return rc; };
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(-2); }
+  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+
+  const size_t D = c->D, P = c->P, M = c->M, L = c->L;
+  size_t o = 0;
+  c->oLn1g = o; o += L * D; c->oLn1b = o; o += L * D; c->oLn2g = o; o += L * D; c->oLn2b = o; o += L * D;
+  c->oWqkv = o; o += L * 3 * D * D; c->oWo = o; o += L * D * D;
+  c->oW1 = o; o += L * M * D; c->ob1 = o; o += L * M; c->oW2 = o; o += L * D * M; c->ob2 = o; o += L * D;
+  c->oWp = o; o += D * P; c->obp = o; o += D; c->oWout = o; o += P * D; c->obout = o; o += P;
+  c->nW = o;
+
+  int rc = 0;
+#define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
+  DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
+  DA(c->pos, (long long)c->N * D);
+  DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
+  DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
+  DA(c->xp, c->n0); DA(c->ximg, c->nImg);
+  c->Gmax = c->L > 0 ? c->L : 1;
+  const long long rows = (long long)c->Gmax * c->BN;
+  DA(c->xn1, rows * D); DA(c->st1, rows * 2); DA(c->qkv, rows * 3 * D); DA(c->att, rows * D); DA(c->lse, rows * c->H);
+  DA(c->y, rows * D); DA(c->xn2, rows * D); DA(c->st2, rows * 2); DA(c->a, rows * M);
+  DA(c->da, rows * M); DA(c->dzn, rows * D); DA(c->dy, rows * D); DA(c->dO, rows * D); DA(c->delta, rows * c->H);
+  DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
+  DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
+  DA(c->gscale, 64); DA(c->eta_dev, c->Tmax);
+  float* tmp = nullptr;
+  DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;
+  DA(tmp, 2LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
+  DA(tmp, 8); c->scal = (double*)tmp;
+#undef DA
+  // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
+  float gs[64];
+  for (int l = 0; l <= c->L + 1; ++l) {
+    float s = 1.f;
+    if (cfg->use_scaling) s = (float)pow((double)cfg->scale_base, (double)(c->L + 1 - l));
+    c->scale_l[l] = s;
+  }
+  for (int g = 0; g < 64; ++g) gs[g] = (g < c->L) ? c->scale_l[g + 1] : 1.f;
+  if (hipMemcpyAsync(c->gscale, gs, sizeof gs, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+      hipStreamSynchronize(c->st) != hipSuccess) { c->err = "initial upload failed"; return fail(-2); }
+  // Launch every kernel of the inference step once outside stream capture (code-object load,
+  // dynamic-LDS attributes).  All state is zero and eta = 0, so nothing observable changes.
+  rc = enqueue_infer(c, 1);
+  if (rc) return fail(rc);
+  if (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) { c->err = "warm-up step failed"; return fail(-2); }
+  c->warmed = true;
+  *out = c;
+  return 0;
+}
+
+int cora_destroy(cora_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->st) hipStreamSynchronize(c->st);
+  for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->st) hipStreamDestroy(c->st);
+  delete c;
+  return 0;
+}
+
+int cora_sync(cora_ctx* c) {
+  if (!c) return -1;
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int cora_weights_size(const cora_ctx* c, size_t* n) {
+  if (!c || !n) return -1;
+  *n = c->nW;
+  return 0;
+}
+
+int cora_weight_offset(const cora_ctx* cc, const char* key, size_t* offset, size_t* count) {
+  cora_ctx* c = const_cast<cora_ctx*>(cc);
+  if (!c || !key || !offset || !count) return -1;
+  const size_t D = c->D, P = c->P, M = c->M;
+  std::string k(key);
+  auto set = [&](size_t o, size_t n) { *offset = o; *count = n; return 0; };
+  if (k == ".patch_projection.nn.weight") return set(c->oWp, D * P);
+  if (k == ".patch_projection.nn.bias") return set(c->obp, D);
+  if (k == ".output_projection.nn.weight") return set(c->oWout, P * D);
+  if (k == ".output_projection.nn.bias") return set(c->obout, P);
+  const char* pre = ".transformer_blocks[";
+  if (k.compare(0, strlen(pre), pre) == 0) {
+    size_t close = k.find(']');
+    if (close == std::string::npos) FAIL(-4, "malformed key: " + k);
+    char* endp = nullptr;
+    long i = strtol(k.c_str() + strlen(pre), &endp, 10);
+    if (endp != k.c_str() + close || i < 0 || i >= c->L) FAIL(-4, "block index out of range: " + k);
+    std::string leaf = k.substr(close + 1);
+    if (leaf == ".layer_norm1.nn.weight") return set(c->oLn1g + i * D, D);
+    if (leaf == ".layer_norm1.nn.bias") return set(c->oLn1b + i * D, D);
+    if (leaf == ".layer_norm2.nn.weight") return set(c->oLn2g + i * D, D);
+    if (leaf == ".layer_norm2.nn.bias") return set(c->oLn2b + i * D, D);
+    if (leaf == ".attention.nn.query_proj.weight") return set(c->oWqkv + i * 3 * D * D, D * D);
+    if (leaf == ".attention.nn.key_proj.weight") return set(c->oWqkv + i * 3 * D * D + D * D, D * D);
+    if (leaf == ".attention.nn.value_proj.weight") return set(c->oWqkv + i * 3 * D * D + 2 * D * D, D * D);
+    if (leaf == ".attention.nn.output_proj.weight") return set(c->oWo + i * D * D, D * D);
+    if (leaf == ".linear1.nn.weight") return set(c->oW1 + i * M * D, M * D);
+    if (leaf == ".linear1.nn.bias") return set(c->ob1 + i * M, M);
+    if (leaf == ".linear2.nn.weight") return set(c->oW2 + i * D * M, D * M);
+    if (leaf == ".linear2.nn.bias") return set(c->ob2 + i * D, D);
+  }
+  FAIL(-4, "unknown parameter key: " + k);
+}
+
+static int copy_in(cora_ctx* c, float* dst, const float* host, size_t n, size_t expect) {
+  if (!host) FAIL(-1, "null host pointer");
+  if (n != expect) FAIL(-1, "size mismatch");
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipMemcpyAsync(dst, host, n * sizeof(float), hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+static int copy_out(cora_ctx* c, float* host, const float* src, size_t n, size_t expect) {
+  if (!host) FAIL(-1, "null host pointer");
+  if (n != expect) FAIL(-1, "size mismatch");
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipMemcpyAsync(host, src, n * sizeof(float), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int cora_set_weights(cora_ctx* c, const float* host, size_t n) { if (!c) return -1; return copy_in(c, c->W, host, n, c->nW); }
+int cora_get_weights(cora_ctx* c, float* host, size_t n) { if (!c) return -1; return copy_out(c, host, c->W, n, c->nW); }
+int cora_set_pos(cora_ctx* c, const float* host, size_t n) { if (!c) return -1; return copy_in(c, c->pos, host, n, (size_t)c->N * c->D); }
+
+int cora_vode_size(const cora_ctx* c, int l, size_t* n) {
+  if (!c || !n || l < 0 || l > c->L + 1) return -1;
+  *n = (size_t)(l == 0 ? c->n0 : c->nl);
+  return 0;
+}
+int cora_set_vode(cora_ctx* c, int l, const float* host, size_t n) {
+  if (!c) return -1;
+  if (l < 0 || l > c->L + 1) FAIL(-1, "vode index out of range (the sensory vode is set through x)");
+  return copy_in(c, vode_ptr(c, c->Hs, l), host, n, (size_t)(l == 0 ? c->n0 : c->nl));
+}
+int cora_get_vode(cora_ctx* c, int l, float* host, size_t n) {
+  if (!c) return -1;
+  if (l < 0 || l > c->L + 1) FAIL(-1, "vode index out of range");
+  return copy_out(c, host, vode_ptr(c, c->Hs, l), n, (size_t)(l == 0 ? c->n0 : c->nl));
+}
+int cora_get_vode_grad(cora_ctx* c, int l, float* host, size_t n) {
+  if (!c) return -1;
+  if (l < 0 || l > c->L + 1) FAIL(-1, "vode index out of range");
+  size_t cnt = (size_t)(l == 0 ? c->n0 : c->nl);
+  int rc = copy_out(c, host, vode_ptr(c, c->Gs, l), n, cnt);
+  if (rc) return rc;
+  if (c->cfg.use_grad_norm && c->last_T > 0) {   // normalize_vode_h_gradients, :353-389
+    double ss = 0.0;
+    HCHECK(hipMemcpy(&ss, c->sumsq + (long long)(c->last_T - 1) * (c->L + 2) + l, sizeof(double), hipMemcpyDeviceToHost));
+    float m = (float)((double)c->cfg.grad_norm_target / (sqrt(ss) + 1e-8));
+    for (size_t i = 0; i < cnt; ++i) host[i] *= m;
+  }
+  return 0;
+}
+
+int cora_init_vodes(cora_ctx* c, const float* h0) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  if (h0) HCHECK(hipMemcpyAsync(c->Hs, h0, sizeof(float) * (size_t)c->n0, hipMemcpyHostToDevice, c->st));
+  else HCHECK(hipMemsetAsync(c->Hs, 0, sizeof(float) * (size_t)c->n0, c->st));
+  int rc = chain_forward(c, true);
+  if (rc) return rc;
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int cora_set_adam_state(cora_ctx* c, const float* mu, const float* nu, int64_t count) {
+  if (!c) return -1;
+  int rc = copy_in(c, c->amu, mu, c->nW, c->nW);
+  if (rc) return rc;
+  rc = copy_in(c, c->anu, nu, c->nW, c->nW);
+  if (rc) return rc;
+  c->adam_count = count;
+  return 0;
+}
+int cora_get_adam_state(cora_ctx* c, float* mu, float* nu, int64_t* count) {
+  if (!c) return -1;
+  int rc = copy_out(c, mu, c->amu, c->nW, c->nW);
+  if (rc) return rc;
+  rc = copy_out(c, nu, c->anu, c->nW, c->nW);
+  if (rc) return rc;
+  if (count) *count = c->adam_count;
+  return 0;
+}
+
+int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, float b1, float b2, float eps, float wd) {
+  if (!c) return -1;
+  cora_config& f = c->cfg;
+  bool graph_dirty = (f.clip_h != clip_h) || (f.momentum != momentum);
+  f.clip_h = clip_h; f.momentum = momentum; f.clip_w = clip_w;
+  f.adam_b1 = b1; f.adam_b2 = b2; f.adam_eps = eps; f.adam_wd = wd;
+  if (graph_dirty) {
+    HCHECK(hipSetDevice(c->device));
+    HCHECK(hipStreamSynchronize(c->st));
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+  }
+  return 0;
+}
+
+int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, cora_step_out* out) {
+  if (!c) return -1;
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!eta_h) FAIL(-1, "eta_h is NULL");
+  HCHECK(hipSetDevice(c->device));
+  int rc = upload_x(c, x, x_on_device);
+  if (rc) return rc;
+  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));   // eta_h / x are caller-owned: copied before we return
+  c->last_T = T;
+  if (!c->use_graph || c->prof) {
+    HCHECK(hipEventRecord(c->ev0, c->st));
+    rc = enqueue_infer(c, T);
+    if (rc) return rc;
+    HCHECK(hipEventRecord(c->ev1, c->st));
+  } else {
+    auto it = c->graphs.find(T);
+    if (it == c->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+      rc = enqueue_infer(c, T);
+      hipError_t e = hipStreamEndCapture(c->st, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+      HCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      c->graphs[T] = exec;
+      it = c->graphs.find(T);
+    }
+    HCHECK(hipEventRecord(c->ev0, c->st));
+    HCHECK(hipGraphLaunch(it->second, c->st));
+    HCHECK(hipEventRecord(c->ev1, c->st));
+  }
+  HCHECK(hipStreamSynchronize(c->st));
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    out->infer_ms = ms;
+    std::vector<double> en((size_t)c->L + 3);
+    HCHECK(hipMemcpy(en.data(), c->energies + (long long)(T - 1) * (c->L + 3), sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+    double tot = 0.0;
+    for (double v : en) tot += v;
+    out->final_h_energy = tot;
+  }
+  return 0;
+}
+
+int cora_wgrad(cora_ctx* c, cora_step_out* out) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L, D = c->D, M = c->M, P = c->P;
+  const int R = (int)c->BN;
+  const int slot = c->Tmax;
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  HCHECK(hipMemsetAsync(c->energies + (long long)slot * (L + 3), 0, sizeof(double) * (L + 3), c->st));
+  HCHECK(hipMemsetAsync(c->dW, 0, sizeof(float) * c->nW, c->st));
+  int rc = errors_pass(c, slot);   // learning_step_fn evaluates E at the final vodes, :482-483
+  if (rc) return rc;
+  // dE/dtheta = -(du/dtheta)^T e
+  wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
+  { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
+  wgrad_gemm(c, 1, err_ptr(c, L + 2), P, 0, vode_ptr(c, c->Hs, L + 1), D, 0, c->dW + c->oWout, 0, 0);
+  { KScope s(c, K_OTHER, 0, 4.0 * R * P); launch_colsum(err_ptr(c, L + 2), nullptr, nullptr, c->dW + c->obout, 0, R, 1, P, -1.f, c->st); }
+  if (L > 0) {
+    const float* r = err_ptr(c, 2);
+    const float* xin = vode_ptr(c, c->Hs, 1);
+    rc = block_backward(c, L, 0, xin, r, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const long long sD = (long long)R * D, sM = (long long)R * M, s3 = (long long)R * 3 * D;
+    wgrad_gemm(c, L, r, D, sD, c->a, M, sM, c->dW + c->oW2, (long long)D * M, 1);       // dW2 = -r^T gelu(a)
+    wgrad_gemm(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);  // dW1 = -da^T LN2(y)
+    wgrad_gemm(c, L, c->dy, D, sD, c->att, D, sD, c->dW + c->oWo, (long long)D * D, 0);  // dWo = -dy^T att
+    wgrad_gemm(c, L, c->dqkv, 3 * D, s3, c->xn1, D, sD, c->dW + c->oWqkv, 3LL * D * D, 0);
+    KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
+    launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
+    launch_colsum(c->dzn, c->y, c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->dzn, nullptr, nullptr, c->dW + c->oLn2b, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
+  }
+  HCHECK(hipEventRecord(c->ev1, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    out->learn_ms = ms;
+    std::vector<double> en((size_t)L + 3);
+    HCHECK(hipMemcpy(en.data(), c->energies + (long long)slot * (L + 3), sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+    double tot = 0.0;
+    for (double v : en) tot += v;
+    out->final_w_energy = tot;
+  }
+  return 0;
+}
+
+int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* out) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  HCHECK(hipMemsetAsync(c->scal, 0, sizeof(double) * 4, c->st));
+  { KScope s(c, K_OTHER, 0, 4.0 * c->nW); launch_sumsq(c->dW, (long long)c->nW, scale_by, c->scal, c->st); }
+  c->adam_count += 1;
+  AdamP a; memset(&a, 0, sizeof a);
+  a.w = c->W; a.g = c->dW; a.mu = c->amu; a.nu = c->anu; a.n = (long long)c->nW; a.sumsq = c->scal;
+  a.gscale = scale_by; a.clip = c->cfg.clip_w; a.lr = eta_w; a.b1 = c->cfg.adam_b1; a.b2 = c->cfg.adam_b2;
+  a.eps = c->cfg.adam_eps; a.wd = c->cfg.adam_wd;
+  a.bc1 = (float)(1.0 - pow((double)a.b1, (double)c->adam_count));
+  a.bc2 = (float)(1.0 - pow((double)a.b2, (double)c->adam_count));
+  { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
+  // reconstruction under status "forward" with the updated weights, :488-494
+  int rc = chain_forward(c, false);
+  if (rc) return rc;
+  { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
+  HCHECK(hipEventRecord(c->ev1, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    out->learn_ms += ms;
+    double s = 0.0;
+    HCHECK(hipMemcpy(&s, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost));
+    out->train_mse = s / (double)c->n0;
+  }
+  return 0;
+}
+
+int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, float eta_w, cora_step_out* out) {
+  if (!c) return -1;
+  cora_step_out tmp; memset(&tmp, 0, sizeof tmp);
+  int rc = cora_infer(c, x, x_on_device, T, eta_h, &tmp);
+  if (rc) return rc;
+  rc = cora_wgrad(c, &tmp);
+  if (rc) return rc;
+  rc = cora_apply_wgrad(c, eta_w, 1.0f / (float)c->B, &tmp);
+  if (rc) return rc;
+  if (out) *out = tmp;
+  return 0;
+}
+
+int cora_wgrad_buffer(cora_ctx* c, void** dev, size_t* n) {
+  if (!c || !dev || !n) return -1;
+  *dev = c->dW; *n = c->nW;
+  return 0;
+}
+int cora_bind_wgrad_buffer(cora_ctx* c, void* dev, size_t n) {
+  if (!c) return -1;
+  if (!dev || n != c->nW) FAIL(-1, "bind_wgrad_buffer: size mismatch");
+  if (((uintptr_t)dev) % 16) FAIL(-1, "bind_wgrad_buffer: pointer must be 16-byte aligned");
+  c->dW = (float*)dev;   // the old buffer stays in c->allocs and is freed with the ctx
+  c->dW_owned = false;
+  return 0;
+}
+int cora_get_wgrad(cora_ctx* c, float* host, size_t n) { if (!c) return -1; return copy_out(c, host, c->dW, n, c->nW); }
+
+int cora_get_energies(cora_ctx* c, int T, double* total, double* per_layer) {
+  if (!c) return -1;
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range");
+  HCHECK(hipSetDevice(c->device));
+  const int W = c->L + 3;
+  std::vector<double> en((size_t)T * W);
+  HCHECK(hipStreamSynchronize(c->st));
+  HCHECK(hipMemcpy(en.data(), c->energies, sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+  for (int t = 0; t < T; ++t) {
+    double s = 0.0;
+    for (int l = 0; l < W; ++l) s += en[(size_t)t * W + l];
+    if (total) total[t] = s;
+  }
+  if (per_layer) memcpy(per_layer, en.data(), sizeof(double) * en.size());
+  return 0;
+}
+
+static int download_image(cora_ctx* c, const float* zpatch, float* host, size_t n) {
+  if (n != (size_t)c->nImg) FAIL(-1, "image size mismatch");
+  launch_patchify(c->ximg, const_cast<float*>(zpatch), c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 1, c->st);
+  HCHECK(hipMemcpyAsync(host, c->ximg, sizeof(float) * n, hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int cora_forward(cora_ctx* c, float* xhat, size_t n) {
+  if (!c) return -1;
+  if (!xhat) FAIL(-1, "null output");
+  HCHECK(hipSetDevice(c->device));
+  int rc = chain_forward(c, false);
+  if (rc) return rc;
+  return download_image(c, c->z, xhat, n);
+}
+
+int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, float* xhat, size_t n) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L, slot = c->Tmax + 1;
+  if (x_host) { int rc = upload_x(c, x_host, 0); if (rc) return rc; }
+  HCHECK(hipMemsetAsync(c->energies + (long long)slot * (L + 3), 0, sizeof(double) * (L + 3), c->st));
+  int rc = errors_pass(c, slot);
+  if (rc) return rc;
+  std::vector<double> en((size_t)L + 3);
+  HCHECK(hipStreamSynchronize(c->st));
+  HCHECK(hipMemcpy(en.data(), c->energies + (long long)slot * (L + 3), sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+  double tot = 0.0;
+  for (double v : en) tot += v;
+  if (E) *E = tot;
+  if (per_layer) memcpy(per_layer, en.data(), sizeof(double) * en.size());
+  if (xhat) {
+    out_proj(c, vode_ptr(c, c->Hs, L + 1), c->z, OUT_STORE, nullptr, nullptr);
+    return download_image(c, c->z, xhat, n);
+  }
+  return 0;
+}
+
+int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* ms, double* flops, double* bytes, int* n_out) {
+  if (!c) return -1;
+  if (cap < K_COUNT) FAIL(-1, "profile: capacity too small");
+  HCHECK(hipSetDevice(c->device));
+  // snapshot the vodes + momentum so profiling does not disturb the trajectory
+  float *hsave = nullptr, *msave = nullptr;
+  HCHECK(hipMalloc((void**)&hsave, sizeof(float) * (size_t)c->nV));
+  HCHECK(hipMalloc((void**)&msave, sizeof(float) * (size_t)c->nV));
+  HCHECK(hipMemcpyAsync(hsave, c->Hs, sizeof(float) * (size_t)c->nV, hipMemcpyDeviceToDevice, c->st));
+  HCHECK(hipMemcpyAsync(msave, c->Ms, sizeof(float) * (size_t)c->nV, hipMemcpyDeviceToDevice, c->st));
+  float eta0 = 0.f;
+  HCHECK(hipStreamSynchronize(c->st));
+  HCHECK(hipMemcpy(c->eta_dev, &eta0, sizeof(float), hipMemcpyHostToDevice));
+  HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (c->L + 3), c->st));
+  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (c->L + 2), c->st));
+  infer_step(c, 0);   // warm
+  HCHECK(hipStreamSynchronize(c->st));
+  c->prof = true; c->recs.clear();
+  const int reps = 5;
+  int rc = 0;
+  for (int i = 0; i < reps && !rc; ++i) rc = infer_step(c, 0);
+  c->prof = false;
+  HCHECK(hipStreamSynchronize(c->st));
+  for (int k = 0; k < K_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; snprintf(names + 32 * k, 32, "%s", kKindNames[k]); }
+  for (auto& r : c->recs) {
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    launches[r.kind] += 1; ms[r.kind] += t; flops[r.kind] += r.flops; bytes[r.kind] += r.bytes;
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  c->recs.clear();
+  if (n_out) *n_out = K_COUNT;
+  HCHECK(hipMemcpyAsync(c->Hs, hsave, sizeof(float) * (size_t)c->nV, hipMemcpyDeviceToDevice, c->st));
+  HCHECK(hipMemcpyAsync(c->Ms, msave, sizeof(float) * (size_t)c->nV, hipMemcpyDeviceToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  hipFree(hsave); hipFree(msave);
+  return rc;
+}
+
+}  // extern "C"

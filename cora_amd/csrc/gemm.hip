@@ -1,0 +1,219 @@
+// gemm.hip -- grouped fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused PC epilogues (gfx950).
+//
+// One kernel template serves every dense contraction of the PC-ViT step
+// (K1 patch projection, K3 QKV, K5 Wo, K6 MLP, K7 output projection, K9/K11/K12
+// backward-data, K14 weight gradients).  C[R,O] = alpha * op(A) * op(B) (+ epilogue), per group
+// (group = transformer block: every block reads its own vode h_l, so all L blocks of one
+// inference step run as ONE grouped launch -- src/decoder_transformer.py:236-239 +
+// pcx/predictive_coding/_vode.py:223-236).
+//
+//   A K-inner : A[row][k]  (activations, row-major)        A K-outer : A[k][row]  (weight-grad: dY^T)
+//   B K-inner : B[col][k]  (eqx Linear weight [out,in])    B K-outer : B[k][col]  (backward-data: W as is)
+//
+// Tile 128x64xBK, 256 threads = 4 waves, wave w owns rows 32w..32w+31 x 64 cols = 2 MFMA tiles.
+// k is permuted inside each 8-deep group so K-inner operands are fetched with one ds_read_b128:
+// MFMA t of group j sees k = 8j + 4*(lane>>5) + t on both operands.
+#include "common.h"
+
+#define BM 128
+#define BN 64
+
+template <int BK, bool AKO, bool BKO>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int LDA_S = AKO ? (BM + 4) : (BK + 4);
+  constexpr int LDB_S = BKO ? (BN + 4) : (BK + 4);
+  constexpr int A_ELEMS = AKO ? BK * (BM + 4) : BM * (BK + 4);
+  constexpr int B_ELEMS = BKO ? BK * (BN + 4) : BN * (BK + 4);
+  __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
+  __shared__ __attribute__((aligned(16))) float Bs[B_ELEMS];
+  __shared__ double red_sh[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int g = blockIdx.z / p.splitk, sk = blockIdx.z % p.splitk;
+  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+
+  const float* A = p.A + (long long)g * p.sA;
+  const float* Bw = p.Bw + (long long)g * p.sB;
+
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int per = (p.K + p.splitk - 1) / p.splitk;
+    per = (per + BK - 1) / BK * BK;
+    kbeg = sk * per;
+    kend = min(p.K, kbeg + per);
+  }
+
+  constexpr int A_V = BM * BK / 4 / 256;  // float4 per thread
+  constexpr int B_V = BN * BK / 4 / 256;
+  static_assert(A_V >= 1 && B_V >= 1, "tile too small");
+  float4 ra[A_V], rb[B_V];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      int f = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!AKO) {
+        int row = f / (BK / 4), kq = f % (BK / 4);
+        int gr = row0 + row, gk = k0 + 4 * kq;
+        if (gr < p.R && gk < kend) v = *reinterpret_cast<const float4*>(A + (long long)gr * p.lda + gk);
+      } else {
+        int k = f / (BM / 4), c4 = f % (BM / 4);
+        int gk = k0 + k, gr = row0 + 4 * c4;
+        if (gk < kend && gr < p.R) v = *reinterpret_cast<const float4*>(A + (long long)gk * p.lda + gr);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      int f = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!BKO) {
+        int col = f / (BK / 4), kq = f % (BK / 4);
+        int gc = col0 + col, gk = k0 + 4 * kq;
+        if (gc < p.O && gk < kend) v = *reinterpret_cast<const float4*>(Bw + (long long)gc * p.ldb + gk);
+      } else {
+        int k = f / (BN / 4), c4 = f % (BN / 4);
+        int gk = k0 + k, gc = col0 + 4 * c4;
+        if (gk < kend && gc < p.O) v = *reinterpret_cast<const float4*>(Bw + (long long)gk * p.ldb + gc);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      int f = tid + 256 * i;
+      float4 v = ra[i];
+      if (!AKO) {
+        if (p.a_gelu) { v.x = cora_gelu(v.x); v.y = cora_gelu(v.y); v.z = cora_gelu(v.z); v.w = cora_gelu(v.w); }
+        int row = f / (BK / 4), kq = f % (BK / 4);
+        *reinterpret_cast<float4*>(&As[row * LDA_S + 4 * kq]) = v;
+      } else {
+        int k = f / (BM / 4), c4 = f % (BM / 4);
+        *reinterpret_cast<float4*>(&As[k * LDA_S + 4 * c4]) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      int f = tid + 256 * i;
+      float4 v = rb[i];
+      if (p.b_gelu) { v.x = cora_gelu(v.x); v.y = cora_gelu(v.y); v.z = cora_gelu(v.z); v.w = cora_gelu(v.w); }
+      if (!BKO) {
+        int col = f / (BK / 4), kq = f % (BK / 4);
+        *reinterpret_cast<float4*>(&Bs[col * LDB_S + 4 * kq]) = v;
+      } else {
+        int k = f / (BN / 4), c4 = f % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[k * LDB_S + 4 * c4]) = v;
+      }
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) load_tiles(k0 + BK);  // prefetch into registers under the MFMAs
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      float a4[4], b4[2][4];
+      if (!AKO) {
+        float4 v = *reinterpret_cast<const float4*>(&As[(32 * w + r) * LDA_S + 8 * j + 4 * hi]);
+        a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a4[t] = As[(8 * j + 4 * hi + t) * LDA_S + 32 * w + r];
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (!BKO) {
+          float4 v = *reinterpret_cast<const float4*>(&Bs[(32 * n + r) * LDB_S + 8 * j + 4 * hi]);
+          b4[n][0] = v.x; b4[n][1] = v.y; b4[n][2] = v.z; b4[n][3] = v.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) b4[n][t] = Bs[(8 * j + 4 * hi + t) * LDB_S + 32 * n + r];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[0][t], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[1][t], acc[1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  const long long offC = (long long)g * p.sC;
+  float* C = p.C + offC;
+  const float* bias = p.bias ? p.bias + (long long)g * p.sBias : nullptr;
+  const float* res1 = p.res1 ? p.res1 + offC : nullptr;
+  const float* res2 = p.res2 ? p.res2 + offC : nullptr;
+  const float* tgt = p.tgt ? p.tgt + offC : nullptr;
+  const float* hreg = p.hreg ? p.hreg + offC : nullptr;
+  const float* aux = p.aux ? p.aux + offC : nullptr;
+  double red = 0.0;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = col0 + 32 * n + r;
+    const float bv = (bias && col < p.O) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = row0 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hi;
+      if (row < p.R && col < p.O) {
+        const long long idx = (long long)row * p.ldc + col;
+        float v = p.alpha * acc[n][i] + bv;
+        if (p.pos) v += p.pos[(long long)(row % p.posN) * p.O + col];
+        if (res1) v += res1[idx];
+        if (res2) v += res2[idx];
+        switch (p.mode) {
+          case OUT_STORE: C[idx] = v; break;
+          case OUT_ERR: {
+            float h = tgt[idx];
+            float e = h - v;
+            C[idx] = e;
+            red += (double)(0.5f * e * e + p.l1 * fabsf(h) + p.l2 * h * h);
+          } break;
+          case OUT_GELUGRAD: C[idx] = v * cora_gelu_grad(aux[idx]); break;
+          case OUT_GRAD: {
+            float own = tgt ? tgt[idx] : 0.f;
+            if (hreg) {
+              float h = hreg[idx];
+              float sg = (h > 0.f) ? 1.f : ((h < 0.f) ? -1.f : 0.f);
+              own += p.l1 * sg + 2.f * p.l2 * h;
+            }
+            float gv = p.alpha2 * (own - v);
+            C[idx] = gv;
+            red += (double)gv * (double)gv;
+          } break;
+          case OUT_ATOMIC: atomicAdd(&C[idx], v); break;
+        }
+      }
+    }
+  }
+  if (p.red) {
+    double tot = block_sum_256(red, red_sh);
+    if (tid == 0) atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+  }
+}
+
+template <int BK>
+static void launch_bk(const GemmP& p, bool ako, bool bko, dim3 grid, hipStream_t st) {
+  if (!ako && !bko) hipLaunchKernelGGL((gemm_kernel<BK, false, false>), grid, dim3(256), 0, st, p);
+  else if (!ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, false, true>), grid, dim3(256), 0, st, p);
+  else if (ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, true, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<BK, true, false>), grid, dim3(256), 0, st, p);
+}
+
+void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
+  dim3 grid((p.R + BM - 1) / BM, (p.O + BN - 1) / BN, p.groups * p.splitk);
+  if (p.K % 32 == 0 && p.splitk == 1) launch_bk<32>(p, a_kouter, b_kouter, grid, st);
+  else launch_bk<16>(p, a_kouter, b_kouter, grid, st);
+}

@@ -1,0 +1,349 @@
+// rowwise.hip -- HBM-bound row-wise and element-wise kernels of the PC step (gfx950):
+// LayerNorm forward/backward (eqx.nn.LayerNorm, /root/reference/pcx/nn/_layer.py:296-315),
+// patchify/unpatchify (/root/reference/src/decoder_transformer.py:259-294), the fused
+// scale/clip/momentum vode update (optax clip_by_global_norm + sgd trace,
+// /root/reference/examples/debug_transformer_wandb.py:1126,1134-1140 via
+// /root/reference/pcx/utils/_optim.py:53-148), bias / LayerNorm parameter gradient column sums,
+// clip + AdamW (/root/reference/examples/debug_transformer_wandb.py:1129,1153-1159) and the
+// clipped reconstruction MSE (/root/reference/src/decoder_transformer.py:491-494).
+// All loads/stores are 16 B per lane; reductions are wave shuffles -> LDS -> one f64 atomic per block.
+#include "common.h"
+
+#define LN_EPS 1e-5f
+
+// 16 lanes per row, float4 per lane, NV float4 per lane (D <= 64*NV)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, long long sParam,
+                                                     float* __restrict__ xn, float* __restrict__ stats,
+                                                     int rows_per_group, long long rows, int D) {
+  const int sub = threadIdx.x & 15;
+  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  const int g = live ? (int)(row / rows_per_group) : 0;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int cidx = 64 * i + 4 * sub;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && cidx < D) v[i] = *reinterpret_cast<const float4*>(x + row * D + cidx);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int cidx = 64 * i + 4 * sub;
+    if (cidx < D) {
+      float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(fmaxf(q / (float)D, 0.f) + LN_EPS);
+  if (!live) return;
+  const float* gm = gamma + (long long)g * sParam;
+  const float* bt = beta + (long long)g * sParam;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int cidx = 64 * i + 4 * sub;
+    if (cidx < D) {
+      float4 gg = *reinterpret_cast<const float4*>(gm + cidx);
+      float4 bb = *reinterpret_cast<const float4*>(bt + cidx);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+      *reinterpret_cast<float4*>(xn + row * D + cidx) = o;
+    }
+  }
+  if (sub == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+  __shared__ double red_sh[4];
+  const int sub = threadIdx.x & 15;
+  const long long rows = (long long)p.rows_per_group * p.groups;
+  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  // all 16 rows of a block belong to one group when rows_per_group % 16 == 0; otherwise handle per row
+  const int g = live ? (int)(row / p.rows_per_group) : 0;
+  const int D = p.D;
+  const float* gm = p.gamma + (long long)g * p.sParam;
+  float mean = 0.f, rstd = 0.f;
+  if (live) { mean = p.stats[2 * row]; rstd = p.stats[2 * row + 1]; }
+  float4 dh[NV], xh[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int cidx = 64 * i + 4 * sub;
+    dh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && cidx < D) {
+      float4 d = *reinterpret_cast<const float4*>(p.dxn + row * D + cidx);
+      float4 xv = *reinterpret_cast<const float4*>(p.x + row * D + cidx);
+      float4 gg = *reinterpret_cast<const float4*>(gm + cidx);
+      dh[i] = make_float4(d.x * gg.x, d.y * gg.y, d.z * gg.z, d.w * gg.w);
+      xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+    }
+    s1 += dh[i].x + dh[i].y + dh[i].z + dh[i].w;
+    s2 += dh[i].x * xh[i].x + dh[i].y * xh[i].y + dh[i].z * xh[i].z + dh[i].w * xh[i].w;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+  double red = 0.0;
+  const float gs = (p.mode == 1 && p.gscale) ? p.gscale[g] : 1.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int cidx = 64 * i + 4 * sub;
+    if (live && cidx < D) {
+      const long long idx = row * D + cidx;
+      float4 rr = *reinterpret_cast<const float4*>(p.r + idx);
+      float dx[4] = {rstd * (dh[i].x - m1 - xh[i].x * m2), rstd * (dh[i].y - m1 - xh[i].y * m2),
+                     rstd * (dh[i].z - m1 - xh[i].z * m2), rstd * (dh[i].w - m1 - xh[i].w * m2)};
+      float rv[4] = {rr.x, rr.y, rr.z, rr.w};
+      float out[4];
+      if (p.mode == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = rv[j] + dx[j];
+      } else {
+        float4 dy4 = *reinterpret_cast<const float4*>(p.dy + idx);
+        float4 ow4 = *reinterpret_cast<const float4*>(p.own + idx);
+        float4 xv4 = *reinterpret_cast<const float4*>(p.x + idx);
+        float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+        float ow[4] = {ow4.x, ow4.y, ow4.z, ow4.w};
+        float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sg = (xv[j] > 0.f) ? 1.f : ((xv[j] < 0.f) ? -1.f : 0.f);
+          float own = ow[j] + p.l1 * sg + 2.f * p.l2 * xv[j];
+          float gv = gs * (own - (rv[j] + dyv[j] + dx[j]));
+          out[j] = gv;
+          red += (double)gv * (double)gv;
+        }
+      }
+      *reinterpret_cast<float4*>(p.out + idx) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+  }
+  if (p.mode == 1 && p.red) {
+    // rows of one block may straddle two groups only if rows_per_group % 16 != 0: reduce per wave then
+    // (each wave = 4 rows) -- the launcher guarantees rows_per_group % 4 == 0.
+    double tot = wave_sum_d(red);
+    if ((threadIdx.x & 63) == 0 && live) atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+    (void)red_sh;
+  }
+}
+
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long long sParam, float* xn,
+                  float* stats, int rows_per_group, int groups, int D, hipStream_t st) {
+  long long rows = (long long)rows_per_group * groups;
+  dim3 grid((unsigned)((rows + 15) / 16));
+  int nv = (D + 63) / 64;
+#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<NVV>), grid, dim3(256), 0, st, x, gamma, beta, sParam, xn, stats, rows_per_group, rows, D)
+  if (nv == 1) LNF(1); else if (nv == 2) LNF(2); else if (nv <= 4) LNF(4); else if (nv <= 6) LNF(6);
+  else if (nv <= 12) LNF(12); else return -1;
+#undef LNF
+  return 0;
+}
+
+int launch_ln_bwd(const LnBwdP& p, hipStream_t st) {
+  long long rows = (long long)p.rows_per_group * p.groups;
+  if (p.rows_per_group % 4 != 0) return -2;
+  dim3 grid((unsigned)((rows + 15) / 16));
+  int nv = (p.D + 63) / 64;
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<NVV>), grid, dim3(256), 0, st, p)
+  if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else if (nv <= 4) LNB(4); else if (nv <= 6) LNB(6);
+  else if (nv <= 12) LNB(12); else return -1;
+#undef LNB
+  return 0;
+}
+
+// ---- patchify: img [B,F,C,H,W] <-> xp [B, N, P], P index = (a*p + b)*C + c  ------------------
+__global__ void patchify_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int F,
+                                int C, int Himg, int Wimg, int p, int to_image) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  // i indexes the image tensor [B,F,C,H,W]
+  int wx = (int)(i % Wimg);
+  long long t = i / Wimg;
+  int hy = (int)(t % Himg); t /= Himg;
+  int c = (int)(t % C); t /= C;
+  int f = (int)(t % F);
+  long long b = t / F;
+  int hp = Himg / p, wp = Wimg / p;
+  int pi = hy / p, a = hy % p, pj = wx / p, bb = wx % p;
+  long long n = ((long long)f * hp + pi) * wp + pj;
+  long long N = (long long)F * hp * wp;
+  int P = p * p * C;
+  long long j = (b * N + n) * P + (a * p + bb) * C + c;
+  if (to_image) dst[i] = src[j]; else dst[j] = src[i];
+}
+void launch_patchify(const float* img, float* xp, int B, int F, int C, int Himg, int Wimg, int p, int to_image,
+                     hipStream_t st) {
+  long long total = (long long)B * F * C * Himg * Wimg;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (to_image) hipLaunchKernelGGL(patchify_kernel, grid, dim3(256), 0, st, xp, (float*)img, total, F, C, Himg, Wimg, p, 1);
+  else hipLaunchKernelGGL(patchify_kernel, grid, dim3(256), 0, st, img, xp, total, F, C, Himg, Wimg, p, 0);
+}
+
+// ---- vode update ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
+  // per-layer multiplier: optional per-leaf normalisation, then the global-norm clip over all leaves
+  __shared__ float mult_sh[64];
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int l = 0; l < p.nlayers; ++l) {
+      double n2 = p.sumsq[l];
+      float m = 1.f;
+      if (p.use_grad_norm) {
+        double nrm = sqrt(n2);
+        m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
+        n2 = n2 * (double)m * (double)m;
+      }
+      mult_sh[l] = m;
+      tot += n2;
+    }
+    float cm = 1.f;
+    if (p.clip > 0.f) {
+      double gn = sqrt(tot);
+      if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
+    }
+    for (int l = 0; l < p.nlayers; ++l) mult_sh[l] *= cm;
+  }
+  __syncthreads();
+  const float eta = p.eta[p.t];
+  const long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    long long e = 4 * i;
+    int l = (e < p.n0) ? 0 : 1 + (int)((e - p.n0) / p.nl);
+    float mul = mult_sh[l];
+    float4 g = *reinterpret_cast<const float4*>(p.g + e);
+    float4 m = *reinterpret_cast<const float4*>(p.m + e);
+    float4 h = *reinterpret_cast<const float4*>(p.h + e);
+    m.x = g.x * mul + p.mu * m.x; m.y = g.y * mul + p.mu * m.y;
+    m.z = g.z * mul + p.mu * m.z; m.w = g.w * mul + p.mu * m.w;
+    h.x -= eta * m.x; h.y -= eta * m.y; h.z -= eta * m.z; h.w -= eta * m.w;
+    *reinterpret_cast<float4*>(p.m + e) = m;
+    *reinterpret_cast<float4*>(p.h + e) = h;
+  }
+}
+void launch_update(const UpdateP& p, hipStream_t st) {
+  long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
+// ---- column sums (bias / LayerNorm parameter gradients) ------------------------------------------
+// grid: (ceil(cols/64), row_chunks, groups); block 256 = 4 row lanes x 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ stats, float* __restrict__ out,
+                                                     long long sOut, int rows_per_group, int cols, float alpha,
+                                                     int rows_per_chunk) {
+  __shared__ float sh[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int g = blockIdx.z;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows_per_group, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < cols) {
+    const float* ap = a + (long long)g * rows_per_group * cols;
+    const float* bp = b ? b + (long long)g * rows_per_group * cols : nullptr;
+    for (int rr = r0 + ry; rr < r1; rr += 4) {
+      float v = ap[(long long)rr * cols + col];
+      if (bp) {
+        float bv = bp[(long long)rr * cols + col];
+        if (stats) {  // b is the LayerNorm input: use its normalised value (x - mean) * rstd
+          long long gr = (long long)g * rows_per_group + rr;
+          bv = (bv - stats[2 * gr]) * stats[2 * gr + 1];
+        }
+        v *= bv;
+      }
+      s += v;
+    }
+  }
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) {
+    float t = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+    atomicAdd(&out[(long long)g * sOut + col], alpha * t);
+  }
+}
+void launch_colsum(const float* a, const float* b, const float* stats, float* out, long long sOut,
+                   int rows_per_group, int groups, int cols, float alpha, hipStream_t st) {
+  int chunk = 256;
+  dim3 grid((cols + 63) / 64, (rows_per_group + chunk - 1) / chunk, groups);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, a, b, stats, out, sOut, rows_per_group, cols, alpha, chunk);
+}
+
+// ---- norms, AdamW, MSE -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ a, long long n, float scale, double* out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double v = (double)(a[i] * scale);
+    s += v * v;
+  }
+  double tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, tot);
+}
+void launch_sumsq(const float* a, long long n, float scale, double* out, hipStream_t st) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, n, scale, out);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamP p) {
+  float cm = 1.f;
+  if (p.clip > 0.f) {
+    double gn = sqrt(p.sumsq[0]);
+    if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
+  }
+  const float gmul = p.gscale * cm;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) {
+    float g = p.g[i] * gmul;
+    float mu = p.b1 * p.mu[i] + (1.f - p.b1) * g;
+    float nu = p.b2 * p.nu[i] + (1.f - p.b2) * g * g;
+    p.mu[i] = mu;
+    p.nu[i] = nu;
+    float mh = mu / p.bc1, nh = nu / p.bc2;
+    float w = p.w[i];
+    float upd = mh / (sqrtf(nh) + p.eps) + p.wd * w;
+    p.w[i] = w - p.lr * upd;
+  }
+}
+void launch_adamw(const AdamP& p, hipStream_t st) {
+  long long blocks = (p.n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                  double* out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float x = fminf(fmaxf(a[i], 0.f), 1.f), y = fminf(fmaxf(b[i], 0.f), 1.f);
+    double d = (double)(x - y);
+    s += d * d;
+  }
+  double tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, tot);
+}
+void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, out);
+}

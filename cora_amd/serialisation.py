@@ -1,0 +1,58 @@
+"""`save_params` / `load_params` in the pcx .npz layout.
+
+Same file format as /root/reference/pcx/utils/_serialisation.py:25-105: one
+`np.savez_compressed` archive keyed by `jtu.keystr(path)` of each selected parameter
+(".patch_projection.nn.weight", ".transformer_blocks[0].attention.nn.query_proj.weight",
+".vodes[0].h", ...), so checkpoints written by the reference driver
+(examples/debug_transformer_wandb.py:1278) load here and vice versa.
+`filter` accepts the same spellings: a class or union of classes out of LayerParam / VodeParam.
+"""
+from __future__ import annotations
+
+from types import UnionType
+from typing import Dict
+
+import numpy as np
+
+from .model import LayerParam, TransformerDecoder, VodeParam
+from .params import vode_key
+
+
+def _wants(filter, cls) -> bool:
+    if isinstance(filter, UnionType):
+        return cls in filter.__args__
+    if isinstance(filter, type):
+        return issubclass(cls, filter)
+    if isinstance(filter, (tuple, list)):
+        return cls in filter
+    raise TypeError("filter must be LayerParam, VodeParam or a union of them")
+
+
+def save_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
+    data: Dict[str, np.ndarray] = {}
+    if _wants(filter, VodeParam):
+        for l in range(model.L + 3):
+            v = model.vodes[l].h.get()
+            if v is not None:
+                data[vode_key(l)] = v
+    if _wants(filter, LayerParam):
+        data.update(model.get_weights())
+    np.savez_compressed(path, **data)
+
+
+def load_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
+    path = path if path.endswith(".npz") else f"{path}.npz"
+    with np.load(path) as loaded:          # allow_pickle stays False
+        if _wants(filter, LayerParam):
+            weights = {}
+            for key in model.param_keys():
+                if key not in loaded:
+                    raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
+                weights[key] = loaded[key]
+            model.set_weights(weights)
+        if _wants(filter, VodeParam):
+            for l in range(model.L + 3):
+                key = vode_key(l)
+                if key not in loaded:
+                    raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
+                model.vodes[l].h.set(loaded[key])

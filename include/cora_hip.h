@@ -1,0 +1,152 @@
+/* cora_hip.h -- C ABI of libcora_hip.so: the MI355X (gfx950) implementation of Cora's PC-ViT
+ * predictive-coding step.
+ *
+ * The reference (/root/reference, pure Python on JAX) has no FFI / plugin interface for this path:
+ * the step is reached by ordinary Python calls.  This ABI is therefore the
+ * boundary a replacement exports and the host package `cora_amd` binds with ctypes; each entry
+ * point cites the reference code it replaces.  All functions return 0 on success and a negative
+ * code on error; cora_last_error() gives the message.  No exceptions cross the ABI, there is no
+ * global state except the per-thread last-error string for failed cora_create calls.
+ *
+ * Ownership / threading: a cora_ctx owns all of its device memory, its HIP stream and its
+ * hipGraphs.  Host buffers are caller-owned and copied synchronously.  One ctx per GPU; a ctx is
+ * not thread-safe; distinct ctxs are independent.
+ *
+ * Layouts (all float32, row-major, batch-major):
+ *   vode l = 0        : [B, N, P]      (h_0, the top latent in patch space)
+ *   vode l = 1..L+1   : [B, N, D]
+ *   images            : [B, C, H, W]  or  [B, F, C, H, W]   (sensory vode, frozen = the input x)
+ *   weights           : one flat arena; cora_weight_offset() maps a pcx key string
+ *                       (".transformer_blocks[3].linear1.nn.weight", ...) to (offset, count).
+ */
+#ifndef CORA_HIP_H
+#define CORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cora_ctx cora_ctx;
+
+/* Static description of one model + step recipe.  Replaces TransformerConfig's derived dims
+ * (src/decoder_transformer.py:100-125) and the optimizer recipe of
+ * examples/debug_transformer_wandb.py:1116-1167. */
+typedef struct cora_config {
+  int32_t N;          /* num_patches (tokens)                                    */
+  int32_t P;          /* patch_dim = p*p*C                                       */
+  int32_t D;          /* hidden_size                                             */
+  int32_t H;          /* num_heads (D % H == 0)                                  */
+  int32_t M;          /* mlp_hidden_dim = int(D*mlp_ratio)                       */
+  int32_t L;          /* num_blocks                                              */
+  int32_t B;          /* batch size held by THIS ctx (per-GPU shard)             */
+  int32_t C;          /* image channels                                          */
+  int32_t patch;      /* patch_size p                                            */
+  int32_t Himg;       /* image height                                            */
+  int32_t Wimg;       /* image width                                             */
+  int32_t F;          /* frames (1 for images)                                   */
+  int32_t dtype_mode; /* 0 = fp32 MFMA (parity path).  Others are rejected.      */
+  int32_t use_scaling;   /* use_inference_lr_scaling (:449-453)                  */
+  float   scale_base;    /* inference_lr_scale_base (:308-350)                   */
+  float   l1;            /* intermediate_l1_coeff (pcx/predictive_coding/_energy.py:61-68) */
+  float   l2;            /* intermediate_l2_coeff                                */
+  float   clip_h;        /* h_grad_clip_norm, <=0 disables (optax.clip_by_global_norm) */
+  float   clip_w;        /* w_grad_clip_norm, <=0 disables                       */
+  float   momentum;      /* hidden_momentum (optax.sgd trace decay)              */
+  float   adam_b1, adam_b2, adam_eps, adam_wd;   /* optax.adamw                  */
+  int32_t use_grad_norm;    /* use_vode_grad_norm (:353-389)                     */
+  float   grad_norm_target; /* vode_grad_norm_target                             */
+  int32_t max_T;         /* largest T any call will use (sizes the energy log)   */
+} cora_config;
+
+/* Results of one step; replaces the 5-tuple returned by train_on_batch
+ * (src/decoder_transformer.py:499).  Gradient tensors stay on the device and are fetched with
+ * cora_get_vode_grads / cora_get_wgrad. */
+typedef struct cora_step_out {
+  double final_h_energy;   /* energy at the start of the last inference step (h_energies[-1]) */
+  double final_w_energy;   /* energy at the final vodes (learning_step_fn value)               */
+  double train_mse;        /* mean((clip(xhat)-clip(x))^2) under status "forward", :488-494     */
+  float  infer_ms;         /* device time of the T-step graph (HIP events on the ctx stream)    */
+  float  learn_ms;         /* device time of wgrad + optimizer + reconstruction                 */
+} cora_step_out;
+
+/* --- lifetime ----------------------------------------------------------------------------- */
+/* Replaces TransformerDecoder.__init__ (src/decoder_transformer.py:129-218): allocates vodes,
+ * weights, optimizer state and scratch on `device`. */
+int cora_create(const cora_config* cfg, int device, cora_ctx** out);
+int cora_destroy(cora_ctx* ctx);
+const char* cora_last_error(const cora_ctx* ctx /* may be NULL */);
+
+/* --- weights: the LayerParam pytree (pcx/utils/_serialisation.py:25-105) -------------------- */
+int cora_weights_size(const cora_ctx* ctx, size_t* n_floats);
+int cora_weight_offset(const cora_ctx* ctx, const char* pcx_key, size_t* offset, size_t* count);
+int cora_set_weights(cora_ctx* ctx, const float* host, size_t n_floats);
+int cora_get_weights(cora_ctx* ctx, float* host, size_t n_floats);
+/* positional_embedding [N, D] (src/decoder_transformer.py:202-209), a constant of the model */
+int cora_set_pos(cora_ctx* ctx, const float* host, size_t n_floats);
+
+/* --- vodes: VodeParam h (pcx/predictive_coding/_vode.py:198) ------------------------------ */
+int cora_vode_size(const cora_ctx* ctx, int l, size_t* n_floats);
+int cora_set_vode(cora_ctx* ctx, int l, const float* host, size_t n_floats);
+int cora_get_vode(cora_ctx* ctx, int l, float* host, size_t n_floats);
+/* Scaled (and, if enabled, normalised) dE/dh of the last inference step: final_h_grad, :476-478 */
+int cora_get_vode_grad(cora_ctx* ctx, int l, float* host, size_t n_floats);
+/* INIT-status forward (examples/debug_transformer_wandb.py:1204-1211, default rule 'h, u <- u'
+ * pcx/predictive_coding/_vode.py:201): h_0 := h0_host (or zeros if NULL), h_l := u_l chained. */
+int cora_init_vodes(cora_ctx* ctx, const float* h0_host);
+
+/* --- optimizer state of optim_w (optax.adamw: mu, nu, count) -- pcx/utils/_optim.py:47,128 -- */
+int cora_set_adam_state(cora_ctx* ctx, const float* mu, const float* nu, int64_t count);
+int cora_get_adam_state(cora_ctx* ctx, float* mu, float* nu, int64_t* count);
+
+/* Replace the optimizer recipe baked in at cora_create (the reference passes optim_h / optim_w to
+ * every train_on_batch call, src/decoder_transformer.py:393).  Cached hipGraphs are dropped when
+ * a value changes.  AdamW moments and count are kept. */
+int cora_set_optim(cora_ctx* ctx, float clip_h, float momentum, float clip_w, float adam_b1,
+                   float adam_b2, float adam_eps, float adam_wd);
+
+/* --- the step ------------------------------------------------------------------------------- */
+/* Whole train_on_batch (src/decoder_transformer.py:392-499, mode 2): set the sensory vode to x,
+ * zero the vode optimizer state, T x (energy, dE/dh, scale, clip, momentum-SGD) captured in one
+ * hipGraph, then dE/dW at the final vodes, clip + AdamW (scale_by = 1/B), then the "forward"
+ * reconstruction and its clipped MSE.  x: [B,C,H,W] floats on the host (x_on_device=0) or on
+ * this ctx's device (1).  eta_h[T]: vode learning rate per step; eta_w: weight learning rate. */
+int cora_step(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h,
+              float eta_w, cora_step_out* out);
+
+/* The same step split at the data-parallel exchange point: cora_infer + cora_wgrad leave the
+ * LOCAL sum of dE/dW in the wgrad buffer; the host all-reduces that buffer (RCCL) and then calls
+ * cora_apply_wgrad with scale_by = 1/B_total. */
+int cora_infer(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h,
+               cora_step_out* out);
+int cora_wgrad(cora_ctx* ctx, cora_step_out* out);
+int cora_apply_wgrad(cora_ctx* ctx, float eta_w, float scale_by, cora_step_out* out);
+/* Device pointer + length of the flat dE/dW buffer (same layout as the weight arena). */
+int cora_wgrad_buffer(cora_ctx* ctx, void** dev_ptr, size_t* n_floats);
+/* Let the caller own the buffer instead (e.g. a torch tensor used for the all-reduce). */
+int cora_bind_wgrad_buffer(cora_ctx* ctx, void* dev_ptr, size_t n_floats);
+int cora_get_wgrad(cora_ctx* ctx, float* host, size_t n_floats);   /* final_w_grad, :483 */
+
+/* Per-step energies of the last cora_infer: total[T] and per-vode [T, L+3] (index l = vode). */
+int cora_get_energies(cora_ctx* ctx, int T, double* total, double* per_layer);
+
+/* `forward(None, model=...)` under status "forward" (:488-489): xhat [B,C,H,W] to the host. */
+int cora_forward(cora_ctx* ctx, float* xhat_host, size_t n_floats);
+/* `energy(model=...)` (:302-305) with the sensory vode set to x (host, may be NULL to keep the
+ * last one): batch-summed E, per-vode E [L+3] (may be NULL) and the status-None prediction. */
+int cora_energy(cora_ctx* ctx, const float* x_host, double* E, double* per_layer,
+                float* xhat_host, size_t n_floats);
+
+/* --- measurement ---------------------------------------------------------------------------- */
+/* Runs one inference step eagerly with HIP events around every launch and reports, per kernel
+ * kind, launches / total ms / algorithmic FLOPs and bytes.  names: array of `cap` char[32]. */
+int cora_profile_step(cora_ctx* ctx, int cap, char* names, int* launches, double* ms,
+                      double* flops, double* bytes, int* n_out);
+int cora_sync(cora_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORA_HIP_H */
