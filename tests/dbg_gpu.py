@@ -9,7 +9,7 @@ for n in names:
     try:
         try:
             errs = T.run_case(n)
-            print(n, "OK max err", max(errs.values()))
+            top=sorted(errs.items(), key=lambda kv:-kv[1])[:4]; print(n, "OK max err", top)
         except AssertionError as e:
             print(n, "FAIL", str(e)[:3000])
     except Exception:
