@@ -285,7 +285,7 @@ int infer_step(cora_ctx* c, int t) {
   const int L = c->L;
   int rc = errors_pass(c, t);
   if (rc) return rc;
-  double* ss = c->sumsq + (long long)t * (L + 2);
+  double* ss = c->sumsq + (long long)t * (L + 2) * 8;
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
@@ -297,10 +297,10 @@ int infer_step(cora_ctx* c, int t) {
   p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
   p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
-  p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + L + 1;
+  p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
   run_gemm(c, p, false, true);
   if (L > 0) {
-    rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 1);
+    rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
     if (rc) return rc;
   }
   UpdateP u; memset(&u, 0, sizeof u);
@@ -317,7 +317,7 @@ int infer_step(cora_ctx* c, int t) {
 int enqueue_infer(cora_ctx* c, int T) {
   const int L = c->L;
   HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (size_t)T * (L + 3), c->st));
-  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (size_t)T * (L + 2), c->st));
+  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (size_t)T * (L + 2) * 8, c->st));
   HCHECK(hipMemsetAsync(c->Ms, 0, sizeof(float) * (size_t)c->nV, c->st));   // optim_h.init, :414
   for (int t = 0; t < T; ++t) {
     int rc = infer_step(c, t);
@@ -439,7 +439,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->gscale, 64); DA(c->eta_dev, c->Tmax);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;
-  DA(tmp, 2LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
+  DA(tmp, 16LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
   DA(tmp, 8); c->scal = (double*)tmp;
 #undef DA
   // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
@@ -564,8 +564,9 @@ int cora_get_vode_grad(cora_ctx* c, int l, float* host, size_t n) {
   int rc = copy_out(c, host, vode_ptr(c, c->Gs, l), n, cnt);
   if (rc) return rc;
   if (c->cfg.use_grad_norm && c->last_T > 0) {   // normalize_vode_h_gradients, :353-389
-    double ss = 0.0;
-    HCHECK(hipMemcpy(&ss, c->sumsq + (long long)(c->last_T - 1) * (c->L + 2) + l, sizeof(double), hipMemcpyDeviceToHost));
+    double s8[8], ss = 0.0;
+    HCHECK(hipMemcpy(s8, c->sumsq + ((long long)(c->last_T - 1) * (c->L + 2) + l) * 8, sizeof s8, hipMemcpyDeviceToHost));
+    for (double v : s8) ss += v;
     float m = (float)((double)c->cfg.grad_norm_target / (sqrt(ss) + 1e-8));
     for (size_t i = 0; i < cnt; ++i) host[i] *= m;
   }
@@ -843,7 +844,7 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   HCHECK(hipStreamSynchronize(c->st));
   HCHECK(hipMemcpy(c->eta_dev, &eta0, sizeof(float), hipMemcpyHostToDevice));
   HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (c->L + 3), c->st));
-  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (c->L + 2), c->st));
+  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (c->L + 2) * 8, c->st));
   infer_step(c, 0);   // warm
   HCHECK(hipStreamSynchronize(c->st));
   c->prof = true; c->recs.clear();

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
   if (p.red) {
     double tot = block_sum_256(red, red_sh);
-    if (tid == 0) atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+    if (tid == 0) {
+      if (p.mode == OUT_GRAD) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + (blockIdx.x & 7)], tot);
+      else atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+    }
   }
 }
 

@@ -138,8 +138,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   if (p.mode == 1 && p.red) {
     // rows of one block may straddle two groups only if rows_per_group % 16 != 0: reduce per wave then
     // (each wave = 4 rows) -- the launcher guarantees rows_per_group % 4 == 0.
+    // each wave = 4 rows of one group (rows_per_group % 4 == 0); 8 slots per layer spread the
+    // same-address atomic traffic (one word takes ~88 atomics/us)
     double tot = wave_sum_d(red);
-    if ((threadIdx.x & 63) == 0 && live) atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+    if ((threadIdx.x & 63) == 0 && live)
+      atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 7)], tot);
     (void)red_sh;
   }
 }
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int l = 0; l < p.nlayers; ++l) {
-      double n2 = p.sumsq[l];
+      double n2 = 0.0;
+      for (int k = 0; k < 8; ++k) n2 += p.sumsq[l * 8 + k];
       float m = 1.f;
       if (p.use_grad_norm) {
         double nrm = sqrt(n2);

@@ -1,0 +1,77 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Batch sharding + one SUM all-reduce of the flat dE/dW
+buffer must reproduce the unsharded gradient (the energy is a plain sum over images,
+/root/reference/src/decoder_transformer.py:305), and every rank must end with identical weights."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cora_amd.dist import allreduce_sum_, shard_slice
+from oracle import pcvit_np as NP
+from tests.util import make_case
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flat(wg, keys):
+    return np.concatenate([wg[k].reshape(-1) for k in keys])
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = make_case((3, 16, 16), 4, 32, 2, 2, 4, seed=21)
+    W = {k: v.astype(np.float64) for k, v in case["W"].items()}
+    keys = sorted(W)
+    sl = shard_slice(4, rank, world)
+    h = [t[sl].astype(np.float64) for t in case["h"]]
+    xp = NP.patchify(case["x"][sl].astype(np.float64), case["dims"])
+    _, _, _, wg, _ = NP.step_grads(h, W, case["pos"].astype(np.float64), xp, case["dims"], case["hp"], want_wgrad=True)
+    buf = torch.from_numpy(_flat(wg, keys).copy())
+    w = allreduce_sum_(buf)
+    q.put((rank, w, buf.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_wgrad_allreduce_matches_unsharded():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = make_case((3, 16, 16), 4, 32, 2, 2, 4, seed=21)
+    W = {k: v.astype(np.float64) for k, v in case["W"].items()}
+    keys = sorted(W)
+    h = [t.astype(np.float64) for t in case["h"]]
+    xp = NP.patchify(case["x"].astype(np.float64), case["dims"])
+    _, _, _, wg, _ = NP.step_grads(h, W, case["pos"].astype(np.float64), xp, case["dims"], case["hp"], want_wgrad=True)
+    full = _flat(wg, keys)
+    for rank, w, buf in res:
+        assert w == world
+        np.testing.assert_allclose(buf, full, rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(res[0][2], res[1][2])   # replicas identical -> identical AdamW
+
+
+def test_shard_slice():
+    assert shard_slice(200, 3, 8) == slice(75, 100)
+    with pytest.raises(ValueError):
+        shard_slice(10, 0, 4)
+
+
+def test_allreduce_without_process_group_is_identity():
+    t = torch.ones(4)
+    assert allreduce_sum_(t) == 1 and torch.equal(t, torch.ones(4))

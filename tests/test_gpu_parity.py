@@ -150,3 +150,32 @@ def test_init_forward_energy_api():
     rec_ref = R.predictions(ht, Wt, torch.as_tensor(case["pos"], dtype=torch.float64), case["dims"], chain=True)[-1].numpy()
     assert relerr(rec, rec_ref) < TOL
     model.close()
+
+
+@pytest.mark.parametrize("name", ["g_0block", "g_1block", "g_2block_h2_reg_clip", "g_video"])
+def test_golden_vectors(name):
+    """HIP path against the committed fixtures (tests/golden/*.npz, made by make_golden.py)."""
+    import os
+    import cora_amd as ca
+    from tests.golden.make_golden import GOLDEN
+    shape, p, D, H, L, B, T, l1, l2, ch, cw = GOLDEN[name]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    dims = R.Dims(tuple(shape), p, D, H, L)
+    hp = R.Hyper(l1=l1, l2=l2, clip_h=ch, clip_w=cw)
+    case = dict(dims=dims, hp=hp, pos=z["pos"], x=z["x"],
+                W={k[1:]: z[k] for k in z.files if k.startswith("W.")},
+                h=[z[f"h_in{l}"] for l in range(L + 2)])
+    model, optim_w, optim_h = build_model(case)
+    Eh, Ew, gh, gw, mse = ca.train_on_batch(T, case["x"], model=model, optim_w=optim_w, optim_h=optim_h)
+    tot, per = ca.step_energies(model, T)
+    assert relerr(tot, z["energies"]) < TOL
+    assert relerr(per, z["layer_energies"]) < TOL
+    assert abs(Ew - float(z["final_w_energy"])) / float(z["final_w_energy"]) < TOL
+    assert abs(mse - float(z["train_mse"])) / float(z["train_mse"]) < TOL
+    for l in range(L + 2):
+        assert relerr(model.vodes[l].h.get(), z[f"h_out{l}"]) < TOL, l
+        assert relerr(gh[l], z[f"gh{l}"]) < TOL, l
+    gnorm = max(np.abs(z["gW" + k]).max() for k in case["W"])
+    for k in case["W"]:
+        assert np.abs(gw[k] - z["gW" + k]).max() / gnorm < TOL, k
+    model.close()

@@ -1,0 +1,137 @@
+"""Oracle checks that run on CPU: the three known-answer facts the reference's own tests pin,
+autograd-vs-hand-VJP agreement of the two restatements, and the committed golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pcvit_np as NP
+from oracle import pcvit_ref as R
+from tests.golden.make_golden import GOLDEN, generate
+from tests.util import make_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_se_energy_known_answer():
+    # /root/reference/tests/pcx/test_vode.py:55-75: h=[1,2,3], u=[1.5,2.5,3.5] -> 0.5*sum(0.25)=0.375
+    h = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    u = torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64)
+    assert float(R.se_energy(h, u).sum()) == pytest.approx(0.375)
+    assert float(R.regularized_plus_se_energy(h, u, 0.0, 0.0).sum()) == pytest.approx(0.375)
+
+
+def test_integration_energy_is_half_sum_sq():
+    # /root/reference/tests/pcx/test_integration.py:130-131: energy == 0.5*sum((h-u)^2)
+    rng = np.random.default_rng(0)
+    h, u = torch.tensor(rng.standard_normal((4, 5))), torch.tensor(rng.standard_normal((4, 5)))
+    assert float(R.se_energy(h, u).sum()) == pytest.approx(0.5 * float(((h - u) ** 2).sum()))
+
+
+def test_linear_known_answer():
+    # /root/reference/tests/pcx/test_nn.py:25-48 with the fixture of tests/conftest.py:100-106
+    W = torch.tensor([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]], dtype=torch.float64)
+    b = torch.tensor([0.1, 0.2], dtype=torch.float64)
+    x = torch.tensor([0.5, 1.0, 1.5], dtype=torch.float64)
+    y = R.linear(x, W, b).numpy()
+    np.testing.assert_allclose(y, [0.5 + 2.0 + 4.5 + 0.1, 2.0 + 5.0 + 9.0 + 0.2], rtol=1e-12)
+
+
+def test_layernorm_reference_properties():
+    # /root/reference/tests/pcx/test_nn.py:135-165: mean(out) ~ 0 with (1,0); mean(out) ~ 1 with (2,1)
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], dtype=torch.float64)
+    out = R.layer_norm(x, torch.ones(5, dtype=torch.float64), torch.zeros(5, dtype=torch.float64))
+    assert abs(float(out.mean())) < 1e-5
+    out = R.layer_norm(x, 2 * torch.ones(5, dtype=torch.float64), torch.ones(5, dtype=torch.float64))
+    assert abs(float(out.mean()) - 1.0) < 1e-5
+    xn, xh, rstd = NP.ln_fwd(x.numpy(), 2 * np.ones(5), np.ones(5))
+    np.testing.assert_allclose(xn, out.numpy(), rtol=1e-12)
+
+
+def test_gelu_is_tanh_form():
+    a = torch.linspace(-4, 4, 33, dtype=torch.float64)
+    want = torch.nn.functional.gelu(a, approximate="tanh")
+    np.testing.assert_allclose(R.gelu_tanh(a).numpy(), want.numpy(), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(NP.gelu(a.numpy()), want.numpy(), rtol=1e-12, atol=1e-15)
+
+
+def test_patchify_roundtrip_and_channel_innermost():
+    dims = R.Dims((3, 8, 8), 4, 16, 1, 0)
+    img = torch.arange(2 * 3 * 8 * 8, dtype=torch.float64).reshape(2, 3, 8, 8)
+    xp = R.patchify(img, dims)
+    assert xp.shape == (2, 4, 48)
+    np.testing.assert_array_equal(R.unpatchify(xp, dims).numpy(), img.numpy())
+    # /root/reference/src/decoder_transformer.py:277-292: pixel(c, i*p+a, j*p+b) = z[i*wp+j, (a*p+b)*C + c]
+    b, c, i, j, a, bb = 1, 2, 1, 0, 3, 2
+    assert float(xp[b, i * 2 + j, (a * 4 + bb) * 3 + c]) == float(img[b, c, i * 4 + a, j * 4 + bb])
+    np.testing.assert_array_equal(NP.patchify(img.numpy(), dims), xp.numpy())
+
+
+@pytest.mark.parametrize("shape,p,D,H,L,B,l1,l2,clip", [
+    ((3, 16, 16), 4, 32, 2, 2, 3, 0.0, 0.0, 2000.0),
+    ((3, 16, 16), 4, 32, 1, 1, 2, 1e-3, 1e-3, 5.0),
+    ((2, 3, 8, 8), 4, 24, 2, 1, 2, 0.0, 0.0, 2000.0),
+    ((3, 8, 8), 4, 16, 1, 0, 2, 0.0, 0.0, 2000.0),
+])
+def test_autograd_matches_hand_vjp(shape, p, D, H, L, B, l1, l2, clip):
+    case = make_case(shape, p, D, H, L, B, seed=3, l1=l1, l2=l2, clip_h=clip)
+    W = {k: v.astype(np.float64) for k, v in case["W"].items()}
+    h = [t.astype(np.float64) for t in case["h"]]
+    T = 3
+    eta = [0.095] * T
+    out = R.train_on_batch(T, case["x"], W, h, case["pos"], case["dims"], case["hp"], eta, 1e-3)
+    xp = NP.patchify(case["x"].astype(np.float64), case["dims"])
+    h2, en, pl, g = NP.infer(T, xp, W, h, case["pos"].astype(np.float64), case["dims"], case["hp"], eta)
+    np.testing.assert_allclose(en, out["energies"], rtol=1e-12)
+    np.testing.assert_allclose(pl, out["layer_energies"], rtol=1e-11, atol=1e-12)
+    for a, b in zip(h2, out["h"]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+    for a, b in zip(g, out["final_h_grad"]):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-10)
+    E, Es, gg, wg, z = NP.step_grads(h2, W, case["pos"].astype(np.float64), xp, case["dims"], case["hp"], want_wgrad=True)
+    assert E == pytest.approx(out["final_w_energy"], rel=1e-12)
+    assert set(wg) == set(out["w_grad"])
+    for k in wg:
+        np.testing.assert_allclose(wg[k], out["w_grad"][k], rtol=1e-8, atol=1e-10)
+
+
+def test_layer_scaling_exponents():
+    # /root/reference/src/decoder_transformer.py:321-341: factor base^{(L+1) - l}
+    dims = R.Dims((3, 8, 8), 4, 16, 1, 2)
+    hp = R.Hyper(scale_base=2.0)
+    g = [torch.ones(1, dtype=torch.float64) for _ in range(4)]
+    out = R.scale_h_grads(g, dims, hp)
+    assert [float(t) for t in out] == [8.0, 4.0, 2.0, 1.0]
+
+
+def test_clip_by_global_norm_semantics():
+    g = [torch.tensor([3.0]), torch.tensor([4.0])]
+    assert [float(t) for t in R._clip(g, 10.0)] == [3.0, 4.0]          # norm 5 < 10: untouched
+    out = R._clip(g, 2.5)
+    assert float(out[0]) == pytest.approx(1.5) and float(out[1]) == pytest.approx(2.0)
+
+
+def test_lr_schedule_shape():
+    f = R.lr_schedule(0.1, 10, 110, 0.5)
+    assert f(0) == 0.0 and f(5) == pytest.approx(0.05) and f(10) == pytest.approx(0.1)
+    assert f(110) == pytest.approx(0.05) and f(60) == pytest.approx(0.075)
+    g = R.lr_schedule(0.1, 0, 100, 0.5)
+    assert g(0) == pytest.approx(0.1)
+
+
+@pytest.mark.parametrize("name", list(GOLDEN))
+def test_oracle_reproduces_golden(name):
+    path = os.path.join(HERE, "golden", name + ".npz")
+    assert os.path.exists(path), "run tests/golden/make_golden.py"
+    want = np.load(path)
+    got = generate(name)
+    assert set(got) == set(want.files)
+    for k in want.files:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-6, atol=1e-9, err_msg=k)
+
+
+def test_golden_files_all_listed():
+    files = {os.path.basename(f)[:-4] for f in glob.glob(os.path.join(HERE, "golden", "*.npz"))}
+    assert files == set(GOLDEN)
