@@ -124,3 +124,15 @@ struct AdamP {
 void launch_adamw(const AdamP& p, hipStream_t st);
 // red[0] += sum (clip01(a)-clip01(b))^2
 void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st);
+
+// ---- fused per-(block, image) kernel (N = 64, D = 64, H = 1) -----------------------------------------
+struct FusedP {
+  const float* H1; float* E2; float* BP1; const float* W; const float* WT;
+  long long oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2;
+  long long tWqkv, tWo, tW1, tW2;
+  double* energy; int B; float l1, l2;
+};
+int launch_fused_block(const FusedP& p, int L, hipStream_t st);
+void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);
+void launch_grad_finish(float* gbp, const float* e, const float* h, const float* gscale, long long nl, int L,
+                        float l1, float l2, double* red, hipStream_t st);

@@ -18,9 +18,9 @@ namespace {
 
 thread_local std::string g_create_err;
 
-enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_COUNT };
+enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_FUSED, K_GRADFIN, K_COUNT };
 const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd",
-                                   "ln_fwd", "ln_bwd", "vode_update", "other"};
+                                   "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "grad_finish"};
 
 struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
 
@@ -46,6 +46,9 @@ struct cora_ctx {
   int64_t adam_count = 0;
   size_t oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, oWp, obp, oWout, obout;
   float* pos = nullptr;
+  float* WT = nullptr;      // transposed copies for the fused kernel's backward GEMMs
+  size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, nWT = 0;
+  bool fused = false;
 
   // vodes
   float *Hs = nullptr, *Ms = nullptr, *Gs = nullptr, *Es = nullptr;  // Es: e_1..e_{L+1} then e_img
@@ -267,6 +270,22 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   return 0;
 }
 
+// transposed weight copies (W^T) read by the fused kernel's backward GEMMs
+void refresh_wt(cora_ctx* c) {
+  if (!c->fused) return;
+  const int D = c->D, M = c->M, L = c->L;
+  KScope s(c, K_OTHER, 0, 8.0 * c->nWT);
+  launch_transpose(c->W + c->oWqkv, c->WT + c->tWqkv, 3 * D, D, L, c->st);
+  launch_transpose(c->W + c->oWo, c->WT + c->tWo, D, D, L, c->st);
+  launch_transpose(c->W + c->oW1, c->WT + c->tW1, M, D, L, c->st);
+  launch_transpose(c->W + c->oW2, c->WT + c->tW2, D, M, L, c->st);
+}
+
+// flops of one block forward + VJP per image (2 FLOP per MAC): 48 N D^2 + 12 N^2 D
+double block_step_flops(cora_ctx* c) {
+  return (double)c->L * c->B * (48.0 * c->N * c->D * (double)c->D + 12.0 * c->N * (double)c->N * c->D);
+}
+
 // energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
 int errors_pass(cora_ctx* c, int slot) {
   const int L = c->L;
@@ -283,9 +302,26 @@ int errors_pass(cora_ctx* c, int slot) {
 // one inference step t: errors, dE/dh for every un-frozen vode, layer scaling, clip, momentum SGD
 int infer_step(cora_ctx* c, int t) {
   const int L = c->L;
-  int rc = errors_pass(c, t);
-  if (rc) return rc;
+  int rc = 0;
   double* ss = c->sumsq + (long long)t * (L + 2) * 8;
+  if (c->fused) {
+    double* en = c->energies + (long long)t * (L + 3);
+    patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
+    FusedP f; memset(&f, 0, sizeof f);
+    f.H1 = vode_ptr(c, c->Hs, 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gs, 1); f.W = c->W; f.WT = c->WT;
+    f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
+    f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
+    f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
+    f.energy = en + 2; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
+    {
+      KScope s(c, K_FUSED, block_step_flops(c), 4.0 * 4 * L * c->nl);
+      if (launch_fused_block(f, L, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
+    }
+    out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
+  } else {
+    int rc0 = errors_pass(c, t);
+    if (rc0) return rc0;
+  }
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
@@ -299,7 +335,10 @@ int infer_step(cora_ctx* c, int t) {
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
   p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
   run_gemm(c, p, false, true);
-  if (L > 0) {
+  if (c->fused) {
+    KScope s(c, K_GRADFIN, 0, 12.0 * L * c->nl);
+    launch_grad_finish(vode_ptr(c, c->Gs, 1), err_ptr(c, 1), vode_ptr(c, c->Hs, 1), c->gscale, c->nl, L, c->cfg.l1, c->cfg.l2, ss + 8, c->st);
+  } else if (L > 0) {
     rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
     if (rc) return rc;
   }
@@ -426,6 +465,13 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
+  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->L > 0 && getenv("CORA_NO_FUSED") == nullptr);
+  if (c->fused) {
+    size_t t = 0;
+    c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
+    c->nWT = t;
+    DA(c->WT, c->nWT);
+  }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
   DA(c->xp, c->n0); DA(c->ximg, c->nImg);
@@ -538,7 +584,14 @@ static int copy_out(cora_ctx* c, float* host, const float* src, size_t n, size_t
   return 0;
 }
 
-int cora_set_weights(cora_ctx* c, const float* host, size_t n) { if (!c) return -1; return copy_in(c, c->W, host, n, c->nW); }
+int cora_set_weights(cora_ctx* c, const float* host, size_t n) {
+  if (!c) return -1;
+  int rc = copy_in(c, c->W, host, n, c->nW);
+  if (rc) return rc;
+  refresh_wt(c);
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
 int cora_get_weights(cora_ctx* c, float* host, size_t n) { if (!c) return -1; return copy_out(c, host, c->W, n, c->nW); }
 int cora_set_pos(cora_ctx* c, const float* host, size_t n) { if (!c) return -1; return copy_in(c, c->pos, host, n, (size_t)c->N * c->D); }
 
@@ -729,6 +782,7 @@ int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* ou
   a.bc1 = (float)(1.0 - pow((double)a.b1, (double)c->adam_count));
   a.bc2 = (float)(1.0 - pow((double)a.b2, (double)c->adam_count));
   { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
+  refresh_wt(c);
   // reconstruction under status "forward" with the updated weights, :488-494
   int rc = chain_forward(c, false);
   if (rc) return rc;
