@@ -131,6 +131,11 @@ struct FusedP {
   long long oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2;
   long long tWqkv, tWo, tW1, tW2;
   double* energy; int B; float l1, l2;
+  // edge layers (vode 0 / 1 and vode L+1 / sensory), one extra workgroup per image
+  int L; float s0;
+  const float* H0; const float* XP; const float* pos;
+  float* E1; float* EIMG; float* G0; double* sumsq0;
+  long long oWp, obp, oWout, obout, tWp, tWout;
 };
 int launch_fused_block(const FusedP& p, int L, hipStream_t st);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

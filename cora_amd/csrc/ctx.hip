@@ -47,7 +47,7 @@ struct cora_ctx {
   size_t oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, oWp, obp, oWout, obout;
   float* pos = nullptr;
   float* WT = nullptr;      // transposed copies for the fused kernel's backward GEMMs
-  size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, nWT = 0;
+  size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, tWp = 0, tWout = 0, nWT = 0;
   bool fused = false;
 
   // vodes
@@ -279,6 +279,8 @@ void refresh_wt(cora_ctx* c) {
   launch_transpose(c->W + c->oWo, c->WT + c->tWo, D, D, L, c->st);
   launch_transpose(c->W + c->oW1, c->WT + c->tW1, M, D, L, c->st);
   launch_transpose(c->W + c->oW2, c->WT + c->tW2, D, M, L, c->st);
+  launch_transpose(c->W + c->oWp, c->WT + c->tWp, D, c->P, 1, c->st);
+  launch_transpose(c->W + c->oWout, c->WT + c->tWout, c->P, D, 1, c->st);
 }
 
 // flops of one block forward + VJP per image (2 FLOP per MAC): 48 N D^2 + 12 N^2 D
@@ -306,23 +308,28 @@ int infer_step(cora_ctx* c, int t) {
   double* ss = c->sumsq + (long long)t * (L + 2) * 8;
   if (c->fused) {
     double* en = c->energies + (long long)t * (L + 3);
-    patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
     FusedP f; memset(&f, 0, sizeof f);
     f.H1 = vode_ptr(c, c->Hs, 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gs, 1); f.W = c->W; f.WT = c->WT;
     f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
     f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
     f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
     f.energy = en + 2; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
+    f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
+    f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
+    f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
     {
-      KScope s(c, K_FUSED, block_step_flops(c), 4.0 * 4 * L * c->nl);
+      double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
+      KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl);
       if (launch_fused_block(f, L, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     }
-    out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
+    KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
+    launch_grad_finish(vode_ptr(c, c->Gs, 1), err_ptr(c, 1), vode_ptr(c, c->Hs, 1), c->gscale, c->nl, L + 1, c->cfg.l1, c->cfg.l2, ss + 8, c->st);
   } else {
     int rc0 = errors_pass(c, t);
     if (rc0) return rc0;
   }
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
+  if (!c->fused) {
   GemmP p = gemm_base(c);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
   p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
@@ -335,12 +342,10 @@ int infer_step(cora_ctx* c, int t) {
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
   p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
   run_gemm(c, p, false, true);
-  if (c->fused) {
-    KScope s(c, K_GRADFIN, 0, 12.0 * L * c->nl);
-    launch_grad_finish(vode_ptr(c, c->Gs, 1), err_ptr(c, 1), vode_ptr(c, c->Hs, 1), c->gscale, c->nl, L, c->cfg.l1, c->cfg.l2, ss + 8, c->st);
-  } else if (L > 0) {
+  if (L > 0) {
     rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
     if (rc) return rc;
+  }
   }
   UpdateP u; memset(&u, 0, sizeof u);
   u.h = c->Hs; u.m = c->Ms; u.g = c->Gs; u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
@@ -465,10 +470,11 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
-  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->L > 0 && getenv("CORA_NO_FUSED") == nullptr);
+  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && getenv("CORA_NO_FUSED") == nullptr);
   if (c->fused) {
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
+    c->tWp = t; t += D * P; c->tWout = t; t += P * D;
     c->nWT = t;
     DA(c->WT, c->nWT);
   }
@@ -495,7 +501,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     if (cfg->use_scaling) s = (float)pow((double)cfg->scale_base, (double)(c->L + 1 - l));
     c->scale_l[l] = s;
   }
-  for (int g = 0; g < 64; ++g) gs[g] = (g < c->L) ? c->scale_l[g + 1] : 1.f;
+  for (int g = 0; g < 64; ++g) gs[g] = (g <= c->L) ? c->scale_l[g + 1] : 1.f;
   if (hipMemcpyAsync(c->gscale, gs, sizeof gs, hipMemcpyHostToDevice, c->st) != hipSuccess ||
       hipStreamSynchronize(c->st) != hipSuccess) { c->err = "initial upload failed"; return fail(-2); }
   // Launch every kernel of the inference step once outside stream capture (code-object load,

@@ -26,23 +26,27 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[ot] += sum_k T[16 ot + i][k] * xf[k]  for the 64 rows of an LDS tile (weights, K, Q, V or dO rows)
-// -> acc[ot][reg'] = Y[row r][16 ot + 4 grp + reg']
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
+// acc[ot] += sum_k T[16 ot + i][k] * xf[k]  for the 16*NOT rows x 16*NCT columns of an LDS tile
+// (weights, K, Q, V or dO rows; row stride LDT) -> acc[ot][reg'] = Y[row r][16 ot + 4 grp + reg']
+template <int NOT, int NCT, int LDT>
+__device__ __forceinline__ void gemm_tile_g(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    float4 a[4];
+  for (int ct = 0; ct < NCT; ++ct) {
+    float4 a[NOT];
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LD + 16 * ct + 4 * grp]);
+    for (int ot = 0; ot < NOT; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 16 * ct + 4 * grp]);
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * ct + 0], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * ct + 0], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * ct + 1], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * ct + 1], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * ct + 2], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * ct + 2], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * ct + 3], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * ct + 3], acc[ot]);
   }
+}
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
+  gemm_tile_g<4, 4, LD>(t, xf, acc, i, grp);
 }
 
 // acc[ct][reg'] += sum over the 64 tile rows j of T[j][16 ct + 4 grp + reg'] * pf[j -> (tt, reg)]
@@ -121,16 +125,119 @@ __device__ __forceinline__ void ln_bwd_rowT(const float* dout, const float* gam,
 
 }  // namespace
 
+
+// ---- edge layers of one image: vode 0 <-> vode 1 (patch projection) and vode L+1 <-> sensory ------
+//   e_1 = h_1 - (h_0 Wp^T + bp + pos)          g_0 = -s_0 e_1 Wp              (vode 0 has no own energy)
+//   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by grad_finish)
+// (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153)
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int rows, int cols, int ldt, int tid) {
+  const int c4n = cols / 4;
+  for (int f = tid; f < rows * c4n; f += 256) {
+    int rr = f / c4n, c4 = f % c4n;
+    *reinterpret_cast<float4*>(&dst[rr * ldt + 4 * c4]) = *reinterpret_cast<const float4*>(src + (long long)rr * cols + 4 * c4);
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void load_rowT_n(float* f, const float* base, int grp) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    float4 v = *reinterpret_cast<const float4*>(base + 16 * ct + 4 * grp);
+    f[4 * ct] = v.x; f[4 * ct + 1] = v.y; f[4 * ct + 2] = v.z; f[4 * ct + 3] = v.w;
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void store_rowT_n(const float* f, float* base, int grp) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+    *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
+}
+
+__device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
+  constexpr int D = 64, P = 48, LP = 52;   // P = 48 patch dim; LP = padded stride of 48-wide tiles
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  float* sWp = lds;                  // [64][LP]   Wp   [D][P]
+  float* sWpT = sWp + 64 * LP;       // [48][LD]   Wp^T [P][D]
+  float* sWo = sWpT + 48 * LD;       // [48][LD]   Wout [P][D]
+  float* sWoT = sWo + 48 * LD;       // [64][LP]   Wout^T [D][P]
+  copy_to_lds(sWp, p.W + p.oWp, 64, P, LP, tid);
+  copy_to_lds(sWpT, p.WT + p.tWp, P, D, LD, tid);
+  copy_to_lds(sWo, p.W + p.oWout, P, D, LD, tid);
+  copy_to_lds(sWoT, p.WT + p.tWout, D, P, LP, tid);
+  const long long tok = (long long)b * 64 + 16 * w + i;     // token row of this lane
+  float h0[12], h1[16], hl[16], xp[12];
+  load_rowT_n<3>(h0, p.H0 + tok * P, grp);
+  load_rowT_n<4>(h1, p.H1 + tok * D, grp);
+  load_rowT_n<4>(hl, p.H1 + (long long)p.L * p.B * 64 * D + tok * D, grp);
+  load_rowT_n<3>(xp, p.XP + tok * P, grp);
+  __syncthreads();
+  f32x4 acc[4];
+  // ---- top: e_1, energy of vode 1, g_0
+  float e1[16];
+  {
+    float bp[16], ps[16], u[16];
+    load_rowT_n<4>(bp, p.W + p.obp, grp);
+    load_rowT_n<4>(ps, p.pos + (long long)(16 * w + i) * D, grp);
+    zero4(acc); gemm_tile_g<4, 3, LP>(sWp, h0, acc, i, grp); unpack(acc, u);
+    float en = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      e1[k] = h1[k] - (u[k] + bp[k] + ps[k]);
+      en += 0.5f * e1[k] * e1[k] + p.l1 * fabsf(h1[k]) + p.l2 * h1[k] * h1[k];
+    }
+    store_rowT_n<4>(e1, p.E1 + tok * D, grp);
+    double tot = wave_sum_d((double)en);
+    if (lane == 0) atomicAdd(&p.energy[-1], tot);            // energy[] points at vode 2; vode 1 is [-1]
+  }
+  {
+    zero4(acc); gemm_tile_g<3, 4, LD>(sWpT, e1, acc, i, grp);
+    float g0[12];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float v = -p.s0 * acc[k][j]; g0[4 * k + j] = v; ss += (double)v * v; }
+    store_rowT_n<3>(g0, p.G0 + tok * P, grp);
+    ss = wave_sum_d(ss);
+    if (lane == 0) atomicAdd(&p.sumsq0[(b * 4 + w) & 7], ss);
+  }
+  // ---- bottom: e_img, energy of the sensory vode, bp_{L+1}
+  {
+    float bo[12], ei[12];
+    load_rowT_n<3>(bo, p.W + p.obout, grp);
+    zero4(acc); gemm_tile_g<3, 4, LD>(sWo, hl, acc, i, grp);
+    float en = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float e = xp[4 * k + j] - (acc[k][j] + bo[4 * k + j]); ei[4 * k + j] = e; en += 0.5f * e * e; }
+    store_rowT_n<3>(ei, p.EIMG + tok * P, grp);
+    double tot = wave_sum_d((double)en);
+    if (lane == 0) atomicAdd(&p.energy[p.L], tot);           // vode L+2
+    zero4(acc); gemm_tile_g<4, 3, LP>(sWoT, ei, acc, i, grp);
+    float bpl[16];
+    unpack(acc, bpl);
+    store_rowT_n<4>(bpl, p.BP1 + (long long)p.L * p.B * 64 * D + tok * D, grp);
+  }
+}
+
 // D = 64, M = 256, N = 64, H = 1
 __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   constexpr int D = 64, M = 256;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
+    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
+    return;
+  }
+  // 4 tiles (69.6 KB) so two workgroups share a CU: K and V persist from the forward into the
+  // backward; the weight double buffer is only live during GEMM phases and is reused for Q and dO
+  // (all 64 tokens) during the attention backward.
   float* bufK = lds;
   float* bufV = lds + TILE;
-  float* bufQ = lds + 2 * TILE;
-  float* bufDO = lds + 3 * TILE;
-  float* wbuf = lds + 4 * TILE;          // 2 tiles
-  float* rowc = lds + 6 * TILE;          // lse2[64], delta[64]
+  float* wbuf = lds + 2 * TILE;          // 2 tiles
+  float* bufQ = lds + 2 * TILE;          // aliases wbuf[0]
+  float* bufDO = lds + 3 * TILE;         // aliases wbuf[1]
+  float* rowc = lds + 4 * TILE;          // lse2[64], delta[64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, grp = lane >> 4;
@@ -150,30 +257,35 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   const float* WqkvT = p.WT + p.tWqkv + (long long)g * D * 3 * D;  // [D][3D]
 
   // ---- weight tile pipeline: global -> registers (prefetch) -> LDS (double buffered) ------------
-  float4 sr[4];
+  // Named registers + macros (not lambdas over an array: hipcc then keeps the staging registers in
+  // scratch and waits for every global load at once).  Thread t stages float4 #t, t+256, t+512, t+768
+  // of the 64x64 tile: row = f >> 4, 16-byte column = f & 15.
+  float4 sr0, sr1, sr2, sr3;
   int cur = 1;
-  auto prefetch = [&](const float* src, int ldw) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int f = tid + 256 * k;
-      sr[k] = *reinterpret_cast<const float4*>(src + (long long)(f >> 4) * ldw + 4 * (f & 15));
-    }
-  };
-  // publish the prefetched tile; returns the LDS tile to read.  One barrier per tile: the buffer
-  // being overwritten was last read two tiles ago, i.e. before the previous barrier.
-  auto publish = [&]() -> const float* {
-    cur ^= 1;
-    float* dst = wbuf + cur * TILE;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int f = tid + 256 * k;
-      *reinterpret_cast<float4*>(&dst[(f >> 4) * LD + 4 * (f & 15)]) = sr[k];
-    }
-    __syncthreads();
-    return dst;
-  };
+  const int srow = tid >> 4, scol = 4 * (tid & 15);
+#define PREFETCH(SRC, LDW)                                                                        \
+  do {                                                                                            \
+    const float* s_ = (SRC) + (long long)srow * (LDW) + scol;                                     \
+    sr0 = *reinterpret_cast<const float4*>(s_);                                                   \
+    sr1 = *reinterpret_cast<const float4*>(s_ + 16LL * (LDW));                                    \
+    sr2 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                                    \
+    sr3 = *reinterpret_cast<const float4*>(s_ + 48LL * (LDW));                                    \
+  } while (0)
+  // publish the prefetched tile into the other buffer.  One barrier per tile: the buffer being
+  // overwritten was last read two tiles ago, i.e. before the previous barrier.
+#define PUBLISH(TPTR)                                                                             \
+  do {                                                                                            \
+    cur ^= 1;                                                                                     \
+    float* d_ = wbuf + cur * TILE + srow * LD + scol;                                             \
+    *reinterpret_cast<float4*>(d_) = sr0;                                                         \
+    *reinterpret_cast<float4*>(d_ + 16 * LD) = sr1;                                               \
+    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr2;                                               \
+    *reinterpret_cast<float4*>(d_ + 48 * LD) = sr3;                                               \
+    __syncthreads();                                                                              \
+    TPTR = wbuf + cur * TILE;                                                                     \
+  } while (0)
 
-  prefetch(Wqkv, D);
+  PREFETCH(Wqkv, D);
 
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], xh1[17], xin[16];
@@ -187,18 +299,17 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   f32x4 acc[4];
   float qf[16];
   {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
-    const float* t = publish(); prefetch(Wqkv + 64 * D, D);
+    const float* t; PUBLISH(t); PREFETCH(Wqkv + 64 * D, D);
     zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
-    store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
     float kf[16];
-    t = publish(); prefetch(Wqkv + 128 * D, D);
+    PUBLISH(t); PREFETCH(Wqkv + 128 * D, D);
     zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
     store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
-    t = publish(); prefetch(Wo, D);
+    PUBLISH(t); PREFETCH(Wo, D);
     zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
     store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
   }
-  __syncthreads();   // K, V, Q of all 64 tokens visible
+  __syncthreads();   // K, V of all 64 tokens visible
   // attention: S[key][q] -> softmax over keys -> O
   float pf[16];
   const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
@@ -221,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   {
     float of[16];
     zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
-    const float* t = publish(); prefetch(W1, D);       // Wo
+    const float* t; PUBLISH(t); PREFETCH(W1, D);       // Wo
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
@@ -235,8 +346,8 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     // a = LN2(y) W1^T + b1   (4 row tiles of W1)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const float* t = publish();
-      if (mt < 3) prefetch(W1 + (mt + 1) * 64 * D, D); else prefetch(W2, M);
+      const float* t; PUBLISH(t);
+      if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D); else PREFETCH(W2, M);
       zero4(acc); gemm_tile(t, zn, acc, i, grp); unpack(acc, &a[16 * mt]);
       float b1[16];
       load_rowT(b1, p.W + p.ob1 + (long long)g * M + 64 * mt, M, grp);
@@ -247,8 +358,8 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     zero4(acc);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      const float* t = publish();
-      if (kc < 3) prefetch(W2 + (kc + 1) * 64, M); else prefetch(W2T, D);
+      const float* t; PUBLISH(t);
+      if (kc < 3) PREFETCH(W2 + (kc + 1) * 64, M); else PREFETCH(W2T, D);
       float gl[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) gl[k] = cora_gelu(a[16 * kc + k]);
@@ -274,8 +385,8 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   // da = (r W2) * gelu'(a), in place over a   (4 row tiles of W2^T)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const float* t = publish();
-    if (mt < 3) prefetch(W2T + (mt + 1) * 64 * D, D); else prefetch(W1T, M);
+    const float* t; PUBLISH(t);
+    if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(W1T, M);
     zero4(acc); gemm_tile(t, r, acc, i, grp);
     float dg[16];
     unpack(acc, dg);
@@ -287,8 +398,8 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     zero4(acc);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      const float* t = publish();
-      if (kc < 3) prefetch(W1T + (kc + 1) * 64, M); else prefetch(WoT, D);
+      const float* t; PUBLISH(t);
+      if (kc < 3) PREFETCH(W1T + (kc + 1) * 64, M); else PREFETCH(WoT, D);
       gemm_tile(t, &a[16 * kc], acc, i, grp);
     }
     float dzn[16], gm[16];
@@ -300,8 +411,10 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   }
   float dof[16];
   {  // dO = dy Wo
-    const float* t = publish(); prefetch(WqkvT, 3 * D);
+    const float* t; PUBLISH(t); PREFETCH(WqkvT, 3 * D);
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
+    __syncthreads();   // every wave is done with the weight buffers: reuse them for Q and dO
+    store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
     store_rowT(dof, &bufDO[(16 * w + i) * LD], grp);
   }
   // attention backward, pass A (own queries): dP, delta, dS, dQ
@@ -320,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) dq[k] *= 0.125f;
   }
-  __syncthreads();   // dO rows and delta of all tokens visible
+  __syncthreads();   // Q, dO rows and delta of all tokens visible
   // pass B (own keys): S, dP recomputed with the key on the lane; dV, dK
   float dk[16], dv[16];
   {
@@ -346,13 +459,15 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) dk[k] *= 0.125f;
   }
+  __syncthreads();     // Q / dO no longer read: the buffers go back to the weight pipeline
   {  // dxn = [dq | dk | dv] Wqkv (3 K-chunks of Wqkv^T), dx = r + dy + LN1^T(dxn)
+    cur = 1;
     zero4(acc);
-    const float* t = publish(); prefetch(WqkvT + 64, 3 * D);
+    const float* t; PUBLISH(t); PREFETCH(WqkvT + 64, 3 * D);
     gemm_tile(t, dq, acc, i, grp);
-    t = publish(); prefetch(WqkvT + 128, 3 * D);
+    PUBLISH(t); PREFETCH(WqkvT + 128, 3 * D);
     gemm_tile(t, dk, acc, i, grp);
-    t = publish();
+    PUBLISH(t);
     gemm_tile(t, dv, acc, i, grp);
     float dxn[16], gm[16], dx[16];
     unpack(acc, dxn);
@@ -364,7 +479,10 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   }
 }
 
-size_t fused_block_lds_bytes() { return (size_t)(6 * TILE + 128) * sizeof(float); }
+#undef PREFETCH
+#undef PUBLISH
+
+size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128) * sizeof(float); }
 
 int launch_fused_block(const FusedP& p, int L, hipStream_t st) {
   static bool attr = false;
@@ -373,7 +491,7 @@ int launch_fused_block(const FusedP& p, int L, hipStream_t st) {
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     attr = true;
   }
-  hipLaunchKernelGGL(pc_block_fused_kernel, dim3(L * p.B), dim3(256), sm, st, p);
+  hipLaunchKernelGGL(pc_block_fused_kernel, dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
 
