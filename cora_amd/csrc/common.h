@@ -136,8 +136,13 @@ struct FusedP {
   const float* H0; const float* XP; const float* pos;
   float* E1; float* EIMG; float* G0; double* sumsq0;
   long long oWp, obp, oWout, obout, tWp, tWout;
+  // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
+  float *S_xn1, *S_xh1, *S_att, *S_xn2, *S_xh2, *S_a, *S_da, *S_dzn, *S_dy, *S_dqkv, *S_dxn;
+  // chain kernel: z [B*N, P] and the clipped squared reconstruction error
+  float* Z; double* mse;
 };
-int launch_fused_block(const FusedP& p, int L, hipStream_t st);
+int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
+int launch_chain(const FusedP& p, int store_h, hipStream_t st);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);
 void launch_grad_finish(float* gbp, const float* e, const float* h, const float* gscale, long long nl, int L,
                         float l1, float l2, double* red, hipStream_t st);

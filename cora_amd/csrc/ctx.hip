@@ -288,6 +288,23 @@ double block_step_flops(cora_ctx* c) {
   return (double)c->L * c->B * (48.0 * c->N * c->D * (double)c->D + 12.0 * c->N * (double)c->N * c->D);
 }
 
+// parameter block of the fused kernels (pc_block_fused / pc_chain)
+void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */, double* ss /* sumsq row */) {
+  const int L = c->L;
+  memset(&f, 0, sizeof f);
+  f.H1 = vode_ptr(c, c->Hs, 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gs, 1); f.W = c->W; f.WT = c->WT;
+  f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
+  f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
+  f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
+  f.energy = en ? en + 2 : nullptr; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
+  f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
+  f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
+  f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
+  f.S_xn1 = c->xn1; f.S_xh1 = c->dO; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_xh2 = c->y; f.S_a = c->a; f.S_da = c->da;
+  f.S_dzn = c->dzn; f.S_dy = c->dy; f.S_dqkv = c->dqkv; f.S_dxn = c->dxn;
+  f.Z = c->z; f.mse = nullptr;
+}
+
 // energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
 int errors_pass(cora_ctx* c, int slot) {
   const int L = c->L;
@@ -308,19 +325,12 @@ int infer_step(cora_ctx* c, int t) {
   double* ss = c->sumsq + (long long)t * (L + 2) * 8;
   if (c->fused) {
     double* en = c->energies + (long long)t * (L + 3);
-    FusedP f; memset(&f, 0, sizeof f);
-    f.H1 = vode_ptr(c, c->Hs, 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gs, 1); f.W = c->W; f.WT = c->WT;
-    f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
-    f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
-    f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
-    f.energy = en + 2; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
-    f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
-    f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
-    f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
+    FusedP f;
+    fill_fused(c, f, en, ss);
     {
       double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
       KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl);
-      if (launch_fused_block(f, L, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
+      if (launch_fused_block(f, L, 0, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     }
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
     launch_grad_finish(vode_ptr(c, c->Gs, 1), err_ptr(c, 1), vode_ptr(c, c->Hs, 1), c->gscale, c->nl, L + 1, c->cfg.l1, c->cfg.l2, ss + 8, c->st);
@@ -372,8 +382,17 @@ int enqueue_infer(cora_ctx* c, int T) {
 
 // status "forward" chain (rule 'h -> u', :167-168,175-176): u_1 from h_0, each block reads the
 // previous u.  If into_vodes, u_l is written into h_l (INIT rule 'h, u <- u').  Leaves z in c->z.
-int chain_forward(cora_ctx* c, bool into_vodes) {
+int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
   const int L = c->L;
+  if (c->fused) {
+    FusedP f;
+    fill_fused(c, f, nullptr, nullptr);
+    f.mse = mse;
+    double fl = (double)c->B * (4.0 * c->N * c->P * c->D + L * (24.0 * c->N * c->D * (double)c->D + 4.0 * c->N * (double)c->N * c->D));
+    KScope s(c, K_OTHER, fl, 0);
+    if (launch_chain(f, into_vodes ? 1 : 0, c->st)) FAIL(-3, "chain kernel launch failed");
+    return 0;
+  }
   float* cur = into_vodes ? vode_ptr(c, c->Hs, 1) : c->ua;
   patch_proj(c, vode_ptr(c, c->Hs, 0), cur, OUT_STORE, nullptr, nullptr);
   for (int i = 0; i < L; ++i) {
@@ -734,8 +753,19 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
   HCHECK(hipEventRecord(c->ev0, c->st));
   HCHECK(hipMemsetAsync(c->energies + (long long)slot * (L + 3), 0, sizeof(double) * (L + 3), c->st));
   HCHECK(hipMemsetAsync(c->dW, 0, sizeof(float) * c->nW, c->st));
-  int rc = errors_pass(c, slot);   // learning_step_fn evaluates E at the final vodes, :482-483
-  if (rc) return rc;
+  int rc = 0;
+  if (c->fused) {
+    // one fused launch evaluates E at the final vodes (:482-483) and leaves every tensor the
+    // weight-gradient contractions need; its vode-gradient outputs go to scratch (final_h_grad stays)
+    FusedP f;
+    fill_fused(c, f, c->energies + (long long)slot * (L + 3), c->sumsq + (long long)(c->Tmax + 1) * (L + 2) * 8);
+    f.BP1 = c->qkv; f.G0 = c->ua;
+    KScope s(c, K_FUSED, block_step_flops(c), 0);
+    if (launch_fused_block(f, L, 1, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
+  } else {
+    rc = errors_pass(c, slot);   // learning_step_fn evaluates E at the final vodes, :482-483
+    if (rc) return rc;
+  }
   // dE/dtheta = -(du/dtheta)^T e
   wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
   { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
@@ -744,8 +774,10 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
   if (L > 0) {
     const float* r = err_ptr(c, 2);
     const float* xin = vode_ptr(c, c->Hs, 1);
-    rc = block_backward(c, L, 0, xin, r, nullptr, nullptr, nullptr);
-    if (rc) return rc;
+    if (!c->fused) {
+      rc = block_backward(c, L, 0, xin, r, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+    }
     const long long sD = (long long)R * D, sM = (long long)R * M, s3 = (long long)R * 3 * D;
     wgrad_gemm(c, L, r, D, sD, c->a, M, sM, c->dW + c->oW2, (long long)D * M, 1);       // dW2 = -r^T gelu(a)
     wgrad_gemm(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);  // dW1 = -da^T LN2(y)
@@ -754,9 +786,9 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
     launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
     launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
-    launch_colsum(c->dzn, c->y, c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->dzn, c->y, c->fused ? nullptr : c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
     launch_colsum(c->dzn, nullptr, nullptr, c->dW + c->oLn2b, D, R, L, D, -1.f, c->st);
-    launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
+    launch_colsum(c->dxn, c->fused ? c->dO : xin, c->fused ? nullptr : c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
     launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
   }
   HCHECK(hipEventRecord(c->ev1, c->st));
@@ -790,9 +822,9 @@ int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* ou
   { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
   refresh_wt(c);
   // reconstruction under status "forward" with the updated weights, :488-494
-  int rc = chain_forward(c, false);
+  int rc = chain_forward(c, false, c->scal + 1);
   if (rc) return rc;
-  { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
+  if (!c->fused) { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {

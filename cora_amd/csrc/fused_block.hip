@@ -221,14 +221,15 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   }
 }
 
-// D = 64, M = 256, N = 64, H = 1
-__global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
+// One transformer block of one image (D = 64, M = 256, N = 64, H = 1).
+//   MODE_INFER: x = h_{g+1} from HBM; writes e_{g+2}, its energy and J^T e (the inference step)
+//   MODE_STORE: the same, and also leaves every tensor the weight-gradient GEMMs need in HBM
+//   MODE_CHAIN: x comes in registers (xio), forward only, the prediction u goes back in xio
+enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, int b, float* xio) {
   constexpr int D = 64, M = 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
-    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
-    return;
-  }
   // 4 tiles (69.6 KB) so two workgroups share a CU: K and V persist from the forward into the
   // backward; the weight double buffer is only live during GEMM phases and is reused for Q and dO
   // (all 64 tokens) during the attention backward.
@@ -241,7 +242,6 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, grp = lane >> 4;
-  const int g = blockIdx.x / p.B, b = blockIdx.x % p.B;
   const long long nl = (long long)p.B * 64 * D;
   const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;   // this lane's token row
   const float* xrow = p.H1 + (long long)g * nl + rowoff;
@@ -289,12 +289,22 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], xh1[17], xin[16];
-  load_rowT(x, xrow, D, grp);
+  if (MODE == MODE_CHAIN) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = xio[k];
+  } else {
+    load_rowT(x, xrow, D, grp);
+  }
+  const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
   {
     float gm[16], bt[16];
     load_rowT(gm, p.W + p.oLn1g + (long long)g * D, D, grp);
     load_rowT(bt, p.W + p.oLn1b + (long long)g * D, D, grp);
     ln_rowT(x, gm, bt, xh1, xin);
+    if (MODE == MODE_STORE) {
+      store_rowT(xin, p.S_xn1 + srow_g * D, grp);
+      store_rowT(xh1, p.S_xh1 + srow_g * D, grp);
+    }
   }
   f32x4 acc[4];
   float qf[16];
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
   {
     float of[16];
     zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
+    if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
     const float* t; PUBLISH(t); PREFETCH(W1, D);       // Wo
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
@@ -343,6 +354,10 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     load_rowT(gm, p.W + p.oLn2g + (long long)g * D, D, grp);
     load_rowT(bt, p.W + p.oLn2b + (long long)g * D, D, grp);
     ln_rowT(y, gm, bt, xh2, zn);
+    if (MODE == MODE_STORE) {
+      store_rowT(zn, p.S_xn2 + srow_g * D, grp);
+      store_rowT(xh2, p.S_xh2 + srow_g * D, grp);
+    }
     // a = LN2(y) W1^T + b1   (4 row tiles of W1)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
       load_rowT(b1, p.W + p.ob1 + (long long)g * M + 64 * mt, M, grp);
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[16 * mt + k] += b1[k];
+      if (MODE == MODE_STORE) store_rowT(&a[16 * mt], p.S_a + srow_g * M + 64 * mt, grp);
     }
     // z = gelu(a) W2^T + b2  (4 K-chunks of W2), u = x + y + z, r = h_next - u
     zero4(acc);
@@ -368,6 +384,11 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     float z[16], b2[16], hn[16];
     unpack(acc, z);
     load_rowT(b2, p.W + p.ob2 + (long long)g * D, D, grp);
+    if (MODE == MODE_CHAIN) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) xio[k] = x[k] + y[k] + z[k] + b2[k];
+      return;
+    }
     load_rowT(hn, hnext, D, grp);
     float en = 0.f;
 #pragma unroll
@@ -392,6 +413,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     unpack(acc, dg);
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[16 * mt + k] = dg[k] * cora_gelu_grad(a[16 * mt + k]);
+    if (MODE == MODE_STORE) store_rowT(&a[16 * mt], p.S_da + srow_g * M + 64 * mt, grp);
   }
   float dy[16];
   {  // dzn = da W1 (4 K-chunks of W1^T), dy = r + LN2^T(dzn)
@@ -408,6 +430,10 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     ln_bwd_rowT(dzn, gm, xh2, dy);
 #pragma unroll
     for (int k = 0; k < 16; ++k) dy[k] += r[k];
+    if (MODE == MODE_STORE) {
+      store_rowT(dzn, p.S_dzn + srow_g * D, grp);
+      store_rowT(dy, p.S_dy + srow_g * D, grp);
+    }
   }
   float dof[16];
   {  // dO = dy Wo
@@ -459,6 +485,11 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) dk[k] *= 0.125f;
   }
+  if (MODE == MODE_STORE) {
+    store_rowT(dq, p.S_dqkv + srow_g * 3 * D, grp);
+    store_rowT(dk, p.S_dqkv + srow_g * 3 * D + D, grp);
+    store_rowT(dv, p.S_dqkv + srow_g * 3 * D + 2 * D, grp);
+  }
   __syncthreads();     // Q / dO no longer read: the buffers go back to the weight pipeline
   {  // dxn = [dq | dk | dv] Wqkv (3 K-chunks of Wqkv^T), dx = r + dy + LN1^T(dxn)
     cur = 1;
@@ -471,6 +502,7 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
     gemm_tile(t, dv, acc, i, grp);
     float dxn[16], gm[16], dx[16];
     unpack(acc, dxn);
+    if (MODE == MODE_STORE) store_rowT(dxn, p.S_dxn + srow_g * D, grp);
     load_rowT(gm, p.W + p.oLn1g + (long long)g * D, D, grp);
     ln_bwd_rowT(dxn, gm, xh1, dx);
 #pragma unroll
@@ -482,16 +514,93 @@ __global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
 #undef PREFETCH
 #undef PUBLISH
 
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
+    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
+    return;
+  }
+  block_body<MODE>(p, lds, blockIdx.x / p.B, blockIdx.x % p.B, nullptr);
+}
+
+// Status "forward" chain (rule 'h -> u', /root/reference/src/decoder_transformer.py:167-168,175-176,
+// 488-489): u_1 from h_0, every block reads the previous block's prediction; one workgroup walks
+// one image through all L blocks.  store_h: also write u_l into h_l (INIT rule 'h, u <- u',
+// /root/reference/pcx/predictive_coding/_vode.py:201).  Writes z = u_{L+1} Wout^T + bout to p.Z and
+// accumulates the clipped reconstruction error (:491-494) into p.mse.
+__global__ __launch_bounds__(256, 1) void pc_chain_kernel(FusedP p, int store_h) {
+  constexpr int D = 64, P = 48, LP = 52;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  const int b = blockIdx.x;
+  const long long tok = (long long)b * 64 + 16 * w + i;
+  const long long nl = (long long)p.B * 64 * D;
+  float x[16];
+  f32x4 acc[4];
+  {
+    copy_to_lds(lds, p.W + p.oWp, 64, P, LP, tid);
+    float h0[12], bp[16], ps[16];
+    load_rowT_n<3>(h0, p.H0 + tok * P, grp);
+    load_rowT_n<4>(bp, p.W + p.obp, grp);
+    load_rowT_n<4>(ps, p.pos + (long long)(16 * w + i) * D, grp);
+    __syncthreads();
+    zero4(acc); gemm_tile_g<4, 3, LP>(lds, h0, acc, i, grp); unpack(acc, x);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] += bp[k] + ps[k];
+    if (store_h) store_rowT(x, const_cast<float*>(p.H1) + tok * D, grp);
+  }
+  for (int g = 0; g < p.L; ++g) {
+    __syncthreads();   // LDS of the previous stage is no longer read
+    block_body<MODE_CHAIN>(p, lds, g, b, x);
+    if (store_h) store_rowT(x, const_cast<float*>(p.H1) + (long long)(g + 1) * nl + tok * D, grp);
+  }
+  __syncthreads();
+  copy_to_lds(lds, p.W + p.oWout, P, D, LD, tid);
+  float bo[12], xp[12];
+  load_rowT_n<3>(bo, p.W + p.obout, grp);
+  load_rowT_n<3>(xp, p.XP + tok * P, grp);
+  __syncthreads();
+  zero4(acc); gemm_tile_g<3, 4, LD>(lds, x, acc, i, grp);
+  float z[12];
+  double se = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[k][j] + bo[4 * k + j];
+      z[4 * k + j] = v;
+      float dd = fminf(fmaxf(v, 0.f), 1.f) - fminf(fmaxf(xp[4 * k + j], 0.f), 1.f);
+      se += (double)dd * dd;
+    }
+  store_rowT_n<3>(z, p.Z + tok * P, grp);
+  if (p.mse) {
+    se = wave_sum_d(se);
+    if (lane == 0) atomicAdd(p.mse, se);
+  }
+}
+
+
 size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128) * sizeof(float); }
 
-int launch_fused_block(const FusedP& p, int L, hipStream_t st) {
+int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st) {
   static bool attr = false;
   size_t sm = fused_block_lds_bytes();
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     attr = true;
   }
-  hipLaunchKernelGGL(pc_block_fused_kernel, dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  if (store) hipLaunchKernelGGL(pc_block_fused_kernel<MODE_STORE>, dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  else hipLaunchKernelGGL(pc_block_fused_kernel<MODE_INFER>, dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  return 0;
+}
+
+int launch_chain(const FusedP& p, int store_h, hipStream_t st) {
+  size_t sm = fused_block_lds_bytes();
+  hipLaunchKernelGGL(pc_chain_kernel, dim3(p.B), dim3(256), sm, st, p, store_h);
   return 0;
 }
 
