@@ -138,6 +138,7 @@ struct FusedP {
   long long oWp, obp, oWout, obout, tWp, tWout;
   // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
   float *S_xn1, *S_xh1, *S_att, *S_xn2, *S_xh2, *S_a, *S_da, *S_dzn, *S_dy, *S_dqkv, *S_dxn;
+  float* S_stash;   // [L*B*N, 3D]: q | P | y parked between forward and backward
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error
   float* Z; double* mse;
 };

@@ -60,7 +60,7 @@ struct cora_ctx {
   int Gmax;
   float *xn1, *st1, *qkv, *att, *lse, *y, *xn2, *st2, *a;
   float *da, *dzn, *dy, *dO, *delta, *dqkv, *dxn;
-  float *ua, *ub, *z;
+  float *ua, *ub, *z, *stash = nullptr;
   float* gscale = nullptr;   // [L] layer scale of the vode each block reads
   float* eta_dev = nullptr;  // [Tmax]
   double* energies = nullptr;  // [(Tmax+2), L+3]
@@ -302,6 +302,7 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
   f.S_xn1 = c->xn1; f.S_xh1 = c->dO; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_xh2 = c->y; f.S_a = c->a; f.S_da = c->da;
   f.S_dzn = c->dzn; f.S_dy = c->dy; f.S_dqkv = c->dqkv; f.S_dxn = c->dxn;
+  f.S_stash = c->stash;
   f.Z = c->z; f.mse = nullptr;
 }
 
@@ -507,6 +508,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->da, rows * M); DA(c->dzn, rows * D); DA(c->dy, rows * D); DA(c->dO, rows * D); DA(c->delta, rows * c->H);
   DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
   DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
+  if (c->fused) DA(c->stash, rows * 3 * D);
   DA(c->gscale, 64); DA(c->eta_dev, c->Tmax);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;

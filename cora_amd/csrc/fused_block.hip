@@ -246,6 +246,14 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;   // this lane's token row
   const float* xrow = p.H1 + (long long)g * nl + rowoff;
   const float* hnext = p.H1 + (long long)(g + 1) * nl + rowoff;
+  const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
+  // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
+  // in the forward and only needed again in the backward (q, P, y, the MLP pre-activation a) are
+  // parked in an L2-resident stash instead of registers and reloaded at their point of use.
+  float* st_q = p.S_stash + srow_g * (3 * D);
+  float* st_p = st_q + D;
+  float* st_y = st_q + 2 * D;
+  float* st_a = p.S_a + srow_g * M;
 
   const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
   const float* Wo = p.W + p.oWo + (long long)g * D * D;
@@ -255,6 +263,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const float* W1T = p.WT + p.tW1 + (long long)g * D * M;      // [D][M]
   const float* WoT = p.WT + p.tWo + (long long)g * D * D;      // [D][D]
   const float* WqkvT = p.WT + p.tWqkv + (long long)g * D * 3 * D;  // [D][3D]
+  const float* ln1g = p.W + p.oLn1g + (long long)g * D;
+  const float* ln1b = p.W + p.oLn1b + (long long)g * D;
+  const float* ln2g = p.W + p.oLn2g + (long long)g * D;
+  const float* ln2b = p.W + p.oLn2b + (long long)g * D;
 
   // ---- weight tile pipeline: global -> registers (prefetch) -> LDS (double buffered) ------------
   // Named registers + macros (not lambdas over an array: hipcc then keeps the staging registers in
@@ -286,115 +298,123 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   } while (0)
 
   PREFETCH(Wqkv, D);
+  const float* t;
+  f32x4 acc[4];
+  const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
 
   // ---- forward ---------------------------------------------------------------------------------------
-  float x[16], xh1[17], xin[16];
+  float x[16], y[16];
   if (MODE == MODE_CHAIN) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = xio[k];
   } else {
     load_rowT(x, xrow, D, grp);
   }
-  const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
   {
-    float gm[16], bt[16];
-    load_rowT(gm, p.W + p.oLn1g + (long long)g * D, D, grp);
-    load_rowT(bt, p.W + p.oLn1b + (long long)g * D, D, grp);
-    ln_rowT(x, gm, bt, xh1, xin);
-    if (MODE == MODE_STORE) {
-      store_rowT(xin, p.S_xn1 + srow_g * D, grp);
-      store_rowT(xh1, p.S_xh1 + srow_g * D, grp);
+    float xin[16];
+    {
+      float gm[16], bt[16], xh[17];
+      load_rowT(gm, ln1g, D, grp);
+      load_rowT(bt, ln1b, D, grp);
+      ln_rowT(x, gm, bt, xh, xin);
+      if (MODE == MODE_STORE) {
+        store_rowT(xin, p.S_xn1 + srow_g * D, grp);
+        store_rowT(xh, p.S_xh1 + srow_g * D, grp);
+      }
     }
-  }
-  f32x4 acc[4];
-  float qf[16];
-  {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
-    const float* t; PUBLISH(t); PREFETCH(Wqkv + 64 * D, D);
-    zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
-    float kf[16];
-    PUBLISH(t); PREFETCH(Wqkv + 128 * D, D);
-    zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
-    store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
-    PUBLISH(t); PREFETCH(Wo, D);
-    zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
-    store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
-  }
-  __syncthreads();   // K, V of all 64 tokens visible
-  // attention: S[key][q] -> softmax over keys -> O
-  float pf[16];
-  const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
-  {
-    zero4(acc); gemm_tile(bufK, qf, acc, i, grp); unpack(acc, pf);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
-    mx = grp_max(mx);
-    float ls = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
-    ls = grp_sum(ls);
-    const float inv = 1.0f / ls;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) pf[k] *= inv;
-    if (grp == 0) rowc[16 * w + i] = mx + __builtin_amdgcn_logf(ls);
-  }
-  float y[16];
-  {
+    float qf[16];
+    {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
+      PUBLISH(t); PREFETCH(Wqkv + 64 * D, D);
+      zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
+      if (MODE != MODE_CHAIN) store_rowT(qf, st_q, grp);
+      float kf[16];
+      PUBLISH(t); PREFETCH(Wqkv + 128 * D, D);
+      zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
+      store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
+      PUBLISH(t); PREFETCH(Wo, D);
+      zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
+      store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
+    }
+    __syncthreads();   // K, V of all 64 tokens visible
+    // attention: S[key][q] -> softmax over keys -> O
     float of[16];
-    zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
-    if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
-    const float* t; PUBLISH(t); PREFETCH(W1, D);       // Wo
+    {
+      float pf[16];
+      zero4(acc); gemm_tile(bufK, qf, acc, i, grp); unpack(acc, pf);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
+      mx = grp_max(mx);
+      float ls = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
+      ls = grp_sum(ls);
+      const float inv = 1.0f / ls;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pf[k] *= inv;
+      if (grp == 0) rowc[16 * w + i] = mx + __builtin_amdgcn_logf(ls);
+      if (MODE != MODE_CHAIN) store_rowT(pf, st_p, grp);
+      zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
+      if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
+    }
+    PUBLISH(t); PREFETCH(W1, D);       // Wo
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
+    if (MODE != MODE_CHAIN) store_rowT(y, st_y, grp);
   }
-  float xh2[17], a[64], r[16];
   {
-    float gm[16], bt[16], zn[16];
-    load_rowT(gm, p.W + p.oLn2g + (long long)g * D, D, grp);
-    load_rowT(bt, p.W + p.oLn2b + (long long)g * D, D, grp);
-    ln_rowT(y, gm, bt, xh2, zn);
-    if (MODE == MODE_STORE) {
-      store_rowT(zn, p.S_xn2 + srow_g * D, grp);
-      store_rowT(xh2, p.S_xh2 + srow_g * D, grp);
+    float zn[16];
+    {
+      float gm[16], bt[16], xh[17];
+      load_rowT(gm, ln2g, D, grp);
+      load_rowT(bt, ln2b, D, grp);
+      ln_rowT(y, gm, bt, xh, zn);
+      if (MODE == MODE_STORE) {
+        store_rowT(zn, p.S_xn2 + srow_g * D, grp);
+        store_rowT(xh, p.S_xh2 + srow_g * D, grp);
+      }
     }
-    // a = LN2(y) W1^T + b1   (4 row tiles of W1)
+    // a_mt = LN2(y) W1[mt]^T + b1 ; z += gelu(a_mt) W2[:, mt]^T   (row tile of W1, K-chunk of W2, interleaved)
+    f32x4 zacc[4];
+    zero4(zacc);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const float* t; PUBLISH(t);
-      if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D); else PREFETCH(W2, M);
-      zero4(acc); gemm_tile(t, zn, acc, i, grp); unpack(acc, &a[16 * mt]);
-      float b1[16];
-      load_rowT(b1, p.W + p.ob1 + (long long)g * M + 64 * mt, M, grp);
+      PUBLISH(t); PREFETCH(W2 + mt * 64, M);
+      float am[16];
+      {
+        float b1[16];
+        load_rowT(b1, p.W + p.ob1 + (long long)g * M + 64 * mt, M, grp);
+        zero4(acc); gemm_tile(t, zn, acc, i, grp); unpack(acc, am);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[16 * mt + k] += b1[k];
-      if (MODE == MODE_STORE) store_rowT(&a[16 * mt], p.S_a + srow_g * M + 64 * mt, grp);
+        for (int k = 0; k < 16; ++k) am[k] += b1[k];
+      }
+      if (MODE != MODE_CHAIN) store_rowT(am, st_a + 64 * mt, grp);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
+      PUBLISH(t);
+      if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D); else PREFETCH(W2T, D);
+      gemm_tile(t, am, zacc, i, grp);
     }
-    // z = gelu(a) W2^T + b2  (4 K-chunks of W2), u = x + y + z, r = h_next - u
-    zero4(acc);
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const float* t; PUBLISH(t);
-      if (kc < 3) PREFETCH(W2 + (kc + 1) * 64, M); else PREFETCH(W2T, D);
-      float gl[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) gl[k] = cora_gelu(a[16 * kc + k]);
-      gemm_tile(t, gl, acc, i, grp);
-    }
-    float z[16], b2[16], hn[16];
-    unpack(acc, z);
+    float z[16], b2[16];
+    unpack(zacc, z);
     load_rowT(b2, p.W + p.ob2 + (long long)g * D, D, grp);
     if (MODE == MODE_CHAIN) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) xio[k] = x[k] + y[k] + z[k] + b2[k];
       return;
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] = x[k] + y[k] + z[k] + b2[k];     // y now holds u
+  }
+  float r[16];
+  {
+    float hn[16];
     load_rowT(hn, hnext, D, grp);
     float en = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      float u = x[k] + y[k] + z[k] + b2[k];
-      r[k] = hn[k] - u;
+      r[k] = hn[k] - y[k];
       en += 0.5f * r[k] * r[k] + p.l1 * fabsf(hn[k]) + p.l2 * hn[k] * hn[k];
     }
     store_rowT(r, p.E2 + (long long)g * nl + rowoff, grp);
@@ -403,31 +423,33 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   }
 
   // ---- backward (cotangent r) -----------------------------------------------------------------------
-  // da = (r W2) * gelu'(a), in place over a   (4 row tiles of W2^T)
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const float* t; PUBLISH(t);
-    if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(W1T, M);
-    zero4(acc); gemm_tile(t, r, acc, i, grp);
-    float dg[16];
-    unpack(acc, dg);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[16 * mt + k] = dg[k] * cora_gelu_grad(a[16 * mt + k]);
-    if (MODE == MODE_STORE) store_rowT(&a[16 * mt], p.S_da + srow_g * M + 64 * mt, grp);
-  }
+  // da_mt = (r W2)[mt] * gelu'(a_mt) ; dzn += da_mt W1[mt]   (row tile of W2^T, K-chunk of W1^T, interleaved)
   float dy[16];
-  {  // dzn = da W1 (4 K-chunks of W1^T), dy = r + LN2^T(dzn)
-    zero4(acc);
+  {
+    f32x4 dacc[4];
+    zero4(dacc);
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const float* t; PUBLISH(t);
-      if (kc < 3) PREFETCH(W1T + (kc + 1) * 64, M); else PREFETCH(WoT, D);
-      gemm_tile(t, &a[16 * kc], acc, i, grp);
+    for (int mt = 0; mt < 4; ++mt) {
+      PUBLISH(t); PREFETCH(W1T + mt * 64, M);
+      float am[16], dg[16];
+      load_rowT(am, st_a + 64 * mt, M, grp);
+      zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dg[k] *= cora_gelu_grad(am[k]);
+      if (MODE == MODE_STORE) store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
+      PUBLISH(t);
+      if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(WoT, D);
+      gemm_tile(t, dg, dacc, i, grp);
     }
-    float dzn[16], gm[16];
-    unpack(acc, dzn);
-    load_rowT(gm, p.W + p.oLn2g + (long long)g * D, D, grp);
-    ln_bwd_rowT(dzn, gm, xh2, dy);
+    // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from the stashed y
+    float dzn[16], gm[16], bt[16], xh[17], yv[16], tmp[16];
+    unpack(dacc, dzn);
+    load_rowT(yv, st_y, D, grp);
+    load_rowT(gm, ln2g, D, grp);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bt[k] = 0.f;
+    ln_rowT(yv, gm, bt, xh, tmp);
+    ln_bwd_rowT(dzn, gm, xh, dy);
 #pragma unroll
     for (int k = 0; k < 16; ++k) dy[k] += r[k];
     if (MODE == MODE_STORE) {
@@ -435,18 +457,20 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       store_rowT(dy, p.S_dy + srow_g * D, grp);
     }
   }
-  float dof[16];
-  {  // dO = dy Wo
-    const float* t; PUBLISH(t); PREFETCH(WqkvT, 3 * D);
+  {  // dO = dy Wo ; from here on r + dy is all that is needed of either
+    float dof[16];
+    PUBLISH(t); PREFETCH(WqkvT, 3 * D);
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] += dy[k];
     __syncthreads();   // every wave is done with the weight buffers: reuse them for Q and dO
-    store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
     store_rowT(dof, &bufDO[(16 * w + i) * LD], grp);
-  }
-  // attention backward, pass A (own queries): dP, delta, dS, dQ
-  float dq[16];
-  {
-    float dp[16];
+    float qf[16];
+    load_rowT(qf, st_q, D, grp);
+    store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
+    // attention backward, pass A (own queries): dP, delta, dS, dQ
+    float pf[16], dp[16];
+    load_rowT(pf, st_p, D, grp);
     zero4(acc); gemm_tile(bufV, dof, acc, i, grp); unpack(acc, dp);     // dP[key][q] = V[key] . dO[q]
     float dl = 0.f;
 #pragma unroll
@@ -455,30 +479,31 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     if (grp == 0) rowc[64 + 16 * w + i] = dl;
 #pragma unroll
     for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);           // dS
-    zero4(acc); accum_tile(bufK, dp, acc, i, grp); unpack(acc, dq);
+    zero4(acc); accum_tile(bufK, dp, acc, i, grp); unpack(acc, dy);      // dy reused: dq
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dq[k] *= 0.125f;
+    for (int k = 0; k < 16; ++k) dy[k] *= 0.125f;
   }
   __syncthreads();   // Q, dO rows and delta of all tokens visible
   // pass B (own keys): S, dP recomputed with the key on the lane; dV, dK
   float dk[16], dv[16];
   {
-    float kf[16], vf[16], sp[16], dp[16];
-    load_rowT(kf, &bufK[(16 * w + i) * LD], LD, grp);
-    load_rowT(vf, &bufV[(16 * w + i) * LD], LD, grp);
-    zero4(acc); gemm_tile(bufQ, kf, acc, i, grp); unpack(acc, sp);      // S[q][key]
-    zero4(acc); gemm_tile(bufDO, vf, acc, i, grp); unpack(acc, dp);     // dP[q][key]
+    float sp[16], dp[16];
+    {
+      float kf[16], vf[16];
+      load_rowT(kf, &bufK[(16 * w + i) * LD], LD, grp);
+      load_rowT(vf, &bufV[(16 * w + i) * LD], LD, grp);
+      zero4(acc); gemm_tile(bufQ, kf, acc, i, grp); unpack(acc, sp);      // S[q][key]
+      zero4(acc); gemm_tile(bufDO, vf, acc, i, grp); unpack(acc, dp);     // dP[q][key]
+    }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       float4 l4 = *reinterpret_cast<const float4*>(&rowc[16 * tt + 4 * grp]);
       float4 d4 = *reinterpret_cast<const float4*>(&rowc[64 + 16 * tt + 4 * grp]);
-      float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float pv = __builtin_amdgcn_exp2f(sp[4 * tt + reg] * sc - lv[reg]);
-        sp[4 * tt + reg] = pv;
-        dp[4 * tt + reg] = pv * (dp[4 * tt + reg] - dvv[reg]);
-      }
+      float pv;
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 0] * sc - l4.x); sp[4 * tt + 0] = pv; dp[4 * tt + 0] = pv * (dp[4 * tt + 0] - d4.x);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 1] * sc - l4.y); sp[4 * tt + 1] = pv; dp[4 * tt + 1] = pv * (dp[4 * tt + 1] - d4.y);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
     }
     zero4(acc); accum_tile(bufDO, sp, acc, i, grp); unpack(acc, dv);    // dV = P^T dO
     zero4(acc); accum_tile(bufQ, dp, acc, i, grp); unpack(acc, dk);     // dK = dS^T Q
@@ -486,7 +511,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     for (int k = 0; k < 16; ++k) dk[k] *= 0.125f;
   }
   if (MODE == MODE_STORE) {
-    store_rowT(dq, p.S_dqkv + srow_g * 3 * D, grp);
+    store_rowT(dy, p.S_dqkv + srow_g * 3 * D, grp);
     store_rowT(dk, p.S_dqkv + srow_g * 3 * D + D, grp);
     store_rowT(dv, p.S_dqkv + srow_g * 3 * D + 2 * D, grp);
   }
@@ -494,20 +519,24 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   {  // dxn = [dq | dk | dv] Wqkv (3 K-chunks of Wqkv^T), dx = r + dy + LN1^T(dxn)
     cur = 1;
     zero4(acc);
-    const float* t; PUBLISH(t); PREFETCH(WqkvT + 64, 3 * D);
-    gemm_tile(t, dq, acc, i, grp);
+    PUBLISH(t); PREFETCH(WqkvT + 64, 3 * D);
+    gemm_tile(t, dy, acc, i, grp);
     PUBLISH(t); PREFETCH(WqkvT + 128, 3 * D);
     gemm_tile(t, dk, acc, i, grp);
     PUBLISH(t);
     gemm_tile(t, dv, acc, i, grp);
-    float dxn[16], gm[16], dx[16];
+    float dxn[16], gm[16], bt[16], xh[17], xv[16], tmp[16];
     unpack(acc, dxn);
     if (MODE == MODE_STORE) store_rowT(dxn, p.S_dxn + srow_g * D, grp);
-    load_rowT(gm, p.W + p.oLn1g + (long long)g * D, D, grp);
-    ln_bwd_rowT(dxn, gm, xh1, dx);
+    load_rowT(xv, xrow, D, grp);          // LN1's normalised input is recomputed from x
+    load_rowT(gm, ln1g, D, grp);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dx[k] += r[k] + dy[k];
-    store_rowT(dx, p.BP1 + (long long)g * nl + rowoff, grp);
+    for (int k = 0; k < 16; ++k) bt[k] = 0.f;
+    ln_rowT(xv, gm, bt, xh, tmp);
+    ln_bwd_rowT(dxn, gm, xh, dk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dk[k] += r[k];        // r holds r + dy
+    store_rowT(dk, p.BP1 + (long long)g * nl + rowoff, grp);
   }
 }
 
@@ -515,7 +544,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #undef PUBLISH
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void pc_block_fused_kernel(FusedP p) {
+__global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
     edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
