@@ -144,17 +144,25 @@ def main():
     barrier()
     t0 = time.perf_counter()
     infer_ms = 0.0
+    trace = []
     for _ in range(args.steps):
         one_step()
         infer_ms += out.infer_ms
+        trace.append((out.final_h_energy, out.final_w_energy, out.train_mse))
+        if os.environ.get("CORA_TRACE") == "2":
+            tot = np.zeros(T)
+            lib.cora_get_energies(ctx, T, tot.ctypes.data_as(C.c_void_p), None)
+            print("per-step E:", ["%.3g" % v for v in tot], file=sys.stderr)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if os.environ.get("CORA_TRACE") == "1":
+        print("trace:", trace, file=sys.stderr)
     if not np.isfinite(out.final_h_energy) or not np.isfinite(out.train_mse):
-        raise SystemExit("non-finite energy / mse in the timed region")
+        raise SystemExit(f"non-finite energy / mse in the timed region: {trace}")
 
     result = None
     if rank == 0:

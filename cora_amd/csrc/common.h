@@ -124,6 +124,7 @@ struct AdamP {
 void launch_adamw(const AdamP& p, hipStream_t st);
 // red[0] += sum (clip01(a)-clip01(b))^2
 void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st);
+void launch_zero(void* ptr, size_t bytes, hipStream_t st);
 
 // ---- fused per-(block, image) kernel (N = 64, D = 64, H = 1) -----------------------------------------
 struct FusedP {
@@ -137,8 +138,9 @@ struct FusedP {
   float* E1; float* EIMG; float* G0; double* sumsq0;
   long long oWp, obp, oWout, obout, tWp, tWout;
   // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
-  float *S_xn1, *S_xh1, *S_att, *S_xn2, *S_xh2, *S_a, *S_da, *S_dzn, *S_dy, *S_dqkv, *S_dxn;
+  float *S_xn1, *S_att, *S_xn2, *S_a, *S_da, *S_dy, *S_dqkv;
   float* S_stash;   // [L*B*N, 3D]: q | P | y parked between forward and backward
+  float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients are accumulated here (null otherwise)
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error
   float* Z; double* mse;
 };

@@ -300,8 +300,8 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
   f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
   f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
-  f.S_xn1 = c->xn1; f.S_xh1 = c->dO; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_xh2 = c->y; f.S_a = c->a; f.S_da = c->da;
-  f.S_dzn = c->dzn; f.S_dy = c->dy; f.S_dqkv = c->dqkv; f.S_dxn = c->dxn;
+  f.S_xn1 = c->xn1; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_a = c->a; f.S_da = c->da;
+  f.S_dy = c->dy; f.S_dqkv = c->dqkv;
   f.S_stash = c->stash;
   f.Z = c->z; f.mse = nullptr;
 }
@@ -371,9 +371,13 @@ int infer_step(cora_ctx* c, int t) {
 
 int enqueue_infer(cora_ctx* c, int T) {
   const int L = c->L;
-  HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (size_t)T * (L + 3), c->st));
-  HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (size_t)T * (L + 2) * 8, c->st));
-  HCHECK(hipMemsetAsync(c->Ms, 0, sizeof(float) * (size_t)c->nV, c->st));   // optim_h.init, :414
+  // Zero-fill KERNELS, not hipMemsetAsync: memset nodes inside the captured graph were observed
+  // (ROCm 7.2, gfx950) to leave the 100 MB momentum buffer stale on some replays, which blew the
+  // vodes up at step 1 of a later batch; tests/test_gpu_parity.py::test_graph_replay_matches_eager
+  // guards this.
+  launch_zero(c->energies, ((sizeof(double) * (size_t)T * (L + 3)) + 15) / 16 * 16, c->st);
+  launch_zero(c->sumsq, sizeof(double) * (size_t)T * (L + 2) * 8, c->st);
+  launch_zero(c->Ms, sizeof(float) * (size_t)c->nV, c->st);   // optim_h.init, :414
   for (int t = 0; t < T; ++t) {
     int rc = infer_step(c, t);
     if (rc) return rc;
@@ -761,7 +765,7 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     // weight-gradient contractions need; its vode-gradient outputs go to scratch (final_h_grad stays)
     FusedP f;
     fill_fused(c, f, c->energies + (long long)slot * (L + 3), c->sumsq + (long long)(c->Tmax + 1) * (L + 2) * 8);
-    f.BP1 = c->qkv; f.G0 = c->ua;
+    f.BP1 = c->qkv; f.G0 = c->ua; f.dW = c->dW;
     KScope s(c, K_FUSED, block_step_flops(c), 0);
     if (launch_fused_block(f, L, 1, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
   } else {
@@ -770,9 +774,9 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
   }
   // dE/dtheta = -(du/dtheta)^T e
   wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
-  { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
+  if (!c->fused) { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
   wgrad_gemm(c, 1, err_ptr(c, L + 2), P, 0, vode_ptr(c, c->Hs, L + 1), D, 0, c->dW + c->oWout, 0, 0);
-  { KScope s(c, K_OTHER, 0, 4.0 * R * P); launch_colsum(err_ptr(c, L + 2), nullptr, nullptr, c->dW + c->obout, 0, R, 1, P, -1.f, c->st); }
+  if (!c->fused) { KScope s(c, K_OTHER, 0, 4.0 * R * P); launch_colsum(err_ptr(c, L + 2), nullptr, nullptr, c->dW + c->obout, 0, R, 1, P, -1.f, c->st); }
   if (L > 0) {
     const float* r = err_ptr(c, 2);
     const float* xin = vode_ptr(c, c->Hs, 1);
@@ -785,13 +789,15 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     wgrad_gemm(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);  // dW1 = -da^T LN2(y)
     wgrad_gemm(c, L, c->dy, D, sD, c->att, D, sD, c->dW + c->oWo, (long long)D * D, 0);  // dWo = -dy^T att
     wgrad_gemm(c, L, c->dqkv, 3 * D, s3, c->xn1, D, sD, c->dW + c->oWqkv, 3LL * D * D, 0);
-    KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
-    launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
-    launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
-    launch_colsum(c->dzn, c->y, c->fused ? nullptr : c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
-    launch_colsum(c->dzn, nullptr, nullptr, c->dW + c->oLn2b, D, R, L, D, -1.f, c->st);
-    launch_colsum(c->dxn, c->fused ? c->dO : xin, c->fused ? nullptr : c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
-    launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
+    if (!c->fused) {   // the fused STORE kernel accumulates these column sums itself
+      KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
+      launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
+      launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
+      launch_colsum(c->dzn, c->y, c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
+      launch_colsum(c->dzn, nullptr, nullptr, c->dW + c->oLn2b, D, R, L, D, -1.f, c->st);
+      launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
+      launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
+    }
   }
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));

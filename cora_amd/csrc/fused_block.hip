@@ -98,6 +98,21 @@ __device__ __forceinline__ void store_rowT(const float* f, float* base, int grp)
     *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
 }
 
+// column sums over the 16 rows of a wave (lanes with equal grp), added to dst[16 ct + 4 grp + reg]:
+// bias / LayerNorm-parameter gradients of the weight step (dE/dtheta = -sum_rows ...)
+template <int NCT>
+__device__ __forceinline__ void colsum_atomic(const float* f, float* dst, float alpha, int i, int grp) {
+#pragma unroll
+  for (int k = 0; k < 4 * NCT; ++k) {
+    float v = f[k];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (i == 0) atomicAdd(&dst[16 * (k >> 2) + 4 * grp + (k & 3)], alpha * v);
+  }
+}
+
 // LayerNorm of a layout-T row (D = 64): xh = (x - mean) * rstd (kept), out = xh * gamma + beta
 __device__ __forceinline__ void ln_rowT(const float* x, const float* gam, const float* bet, float* xh, float* out) {
   float s = 0.f;
@@ -186,6 +201,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
       en += 0.5f * e1[k] * e1[k] + p.l1 * fabsf(h1[k]) + p.l2 * h1[k] * h1[k];
     }
     store_rowT_n<4>(e1, p.E1 + tok * D, grp);
+    if (p.dW) colsum_atomic<4>(e1, p.dW + p.obp, -1.f, i, grp);
     double tot = wave_sum_d((double)en);
     if (lane == 0) atomicAdd(&p.energy[-1], tot);            // energy[] points at vode 2; vode 1 is [-1]
   }
@@ -212,6 +228,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float e = xp[4 * k + j] - (acc[k][j] + bo[4 * k + j]); ei[4 * k + j] = e; en += 0.5f * e * e; }
     store_rowT_n<3>(ei, p.EIMG + tok * P, grp);
+    if (p.dW) colsum_atomic<3>(ei, p.dW + p.obout, -1.f, i, grp);
     double tot = wave_sum_d((double)en);
     if (lane == 0) atomicAdd(&p.energy[p.L], tot);           // vode L+2
     zero4(acc); gemm_tile_g<4, 3, LP>(sWoT, ei, acc, i, grp);
@@ -317,10 +334,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       load_rowT(gm, ln1g, D, grp);
       load_rowT(bt, ln1b, D, grp);
       ln_rowT(x, gm, bt, xh, xin);
-      if (MODE == MODE_STORE) {
-        store_rowT(xin, p.S_xn1 + srow_g * D, grp);
-        store_rowT(xh, p.S_xh1 + srow_g * D, grp);
-      }
+      if (MODE == MODE_STORE) store_rowT(xin, p.S_xn1 + srow_g * D, grp);
     }
     float qf[16];
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
@@ -370,10 +384,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       load_rowT(gm, ln2g, D, grp);
       load_rowT(bt, ln2b, D, grp);
       ln_rowT(y, gm, bt, xh, zn);
-      if (MODE == MODE_STORE) {
-        store_rowT(zn, p.S_xn2 + srow_g * D, grp);
-        store_rowT(xh, p.S_xh2 + srow_g * D, grp);
-      }
+      if (MODE == MODE_STORE) store_rowT(zn, p.S_xn2 + srow_g * D, grp);
     }
     // a_mt = LN2(y) W1[mt]^T + b1 ; z += gelu(a_mt) W2[:, mt]^T   (row tile of W1, K-chunk of W2, interleaved)
     f32x4 zacc[4];
@@ -420,6 +431,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     store_rowT(r, p.E2 + (long long)g * nl + rowoff, grp);
     double tot = wave_sum_d((double)en);
     if (lane == 0) atomicAdd(&p.energy[g], tot);
+    if (MODE == MODE_STORE) colsum_atomic<4>(r, p.dW + p.ob2 + (long long)g * D, -1.f, i, grp);
   }
 
   // ---- backward (cotangent r) -----------------------------------------------------------------------
@@ -436,7 +448,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
 #pragma unroll
       for (int k = 0; k < 16; ++k) dg[k] *= cora_gelu_grad(am[k]);
-      if (MODE == MODE_STORE) store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
+      if (MODE == MODE_STORE) {
+        store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
+        colsum_atomic<4>(dg, p.dW + p.ob1 + (long long)g * M + 64 * mt, -1.f, i, grp);
+      }
       PUBLISH(t);
       if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(WoT, D);
       gemm_tile(t, dg, dacc, i, grp);
@@ -453,8 +468,11 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
     for (int k = 0; k < 16; ++k) dy[k] += r[k];
     if (MODE == MODE_STORE) {
-      store_rowT(dzn, p.S_dzn + srow_g * D, grp);
       store_rowT(dy, p.S_dy + srow_g * D, grp);
+      colsum_atomic<4>(dzn, p.dW + p.oLn2b + (long long)g * D, -1.f, i, grp);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dzn[k] *= xh[k];
+      colsum_atomic<4>(dzn, p.dW + p.oLn2g + (long long)g * D, -1.f, i, grp);
     }
   }
   {  // dO = dy Wo ; from here on r + dy is all that is needed of either
@@ -527,13 +545,18 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     gemm_tile(t, dv, acc, i, grp);
     float dxn[16], gm[16], bt[16], xh[17], xv[16], tmp[16];
     unpack(acc, dxn);
-    if (MODE == MODE_STORE) store_rowT(dxn, p.S_dxn + srow_g * D, grp);
     load_rowT(xv, xrow, D, grp);          // LN1's normalised input is recomputed from x
     load_rowT(gm, ln1g, D, grp);
 #pragma unroll
     for (int k = 0; k < 16; ++k) bt[k] = 0.f;
     ln_rowT(xv, gm, bt, xh, tmp);
     ln_bwd_rowT(dxn, gm, xh, dk);
+    if (MODE == MODE_STORE) {
+      colsum_atomic<4>(dxn, p.dW + p.oLn1b + (long long)g * D, -1.f, i, grp);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dxn[k] *= xh[k];
+      colsum_atomic<4>(dxn, p.dW + p.oLn1g + (long long)g * D, -1.f, i, grp);
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) dk[k] += r[k];        // r holds r + dy
     store_rowT(dk, p.BP1 + (long long)g * nl + rowoff, grp);

@@ -351,3 +351,16 @@ void launch_mse(const float* a, const float* b, long long n, double* out, hipStr
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, out);
 }
+
+// ---- zero fill as a kernel (used inside captured graphs instead of memset nodes) --------------------
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_zero(void* ptr, size_t bytes, hipStream_t st) {   // bytes % 16 == 0, ptr 16-byte aligned
+  long long n4 = (long long)(bytes / 16);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4*)ptr, n4);
+}
