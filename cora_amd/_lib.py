@@ -7,7 +7,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcora_hip.so")
+LIB_PATH = os.environ.get("CORA_HIP_LIB") or os.path.join(_HERE, "libcora_hip.so")   # env: diagnostic builds
 
 
 class CoraConfig(C.Structure):

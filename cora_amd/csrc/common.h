@@ -9,20 +9,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CORA_LOG2E 1.4426950408889634f
 
 // ---- tanh-GELU (jax.nn.gelu approximate=True, pcx/nn/_layer.py:439) -------------------------
-__device__ __forceinline__ float cora_tanhf(float x) {
-  // tanh(x) = 1 - 2/(1+exp(2x)); exp2-based, saturates cleanly for |x| large.
-  float e = __builtin_amdgcn_exp2f(x * (2.0f * CORA_LOG2E));
-  return 1.0f - 2.0f / (1.0f + e);
-}
+// 0.5 a (1 + tanh(u)) = a * sigmoid(2u),  u = c0 (a + c1 a^3).  Written on v_exp_f32 / v_rcp_f32
+// (1 ulp each) with no IEEE division: 7 VALU ops forward, 12 for the derivative.
+//   s = sigmoid(2u) = 1 - 1/(1 + e),  e = exp(2u)       (e = inf -> s = 1, e = 0 -> s = 0)
+//   gelu'(a) = s + a s (1 - s) * 2 c0 (1 + 3 c1 a^2)
+#define CORA_GELU_K0 2.3022081981f    /* 2 * log2(e) * sqrt(2/pi) */
+#define CORA_GELU_K1 0.1029432396f    /* K0 * 0.044715 */
 __device__ __forceinline__ float cora_gelu(float a) {
-  const float c0 = 0.7978845608028654f, c1 = 0.044715f;
-  float t = cora_tanhf(c0 * (a + c1 * a * a * a));
-  return 0.5f * a * (1.0f + t);
+  float a2 = a * a;
+  float e = __builtin_amdgcn_exp2f(a * __builtin_fmaf(CORA_GELU_K1, a2, CORA_GELU_K0));
+  float r = __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_fmaf(-a, r, a);
 }
 __device__ __forceinline__ float cora_gelu_grad(float a) {
-  const float c0 = 0.7978845608028654f, c1 = 0.044715f;
-  float t = cora_tanhf(c0 * (a + c1 * a * a * a));
-  return 0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * c0 * (1.0f + 3.0f * c1 * a * a);
+  float a2 = a * a;
+  float e = __builtin_amdgcn_exp2f(a * __builtin_fmaf(CORA_GELU_K1, a2, CORA_GELU_K0));
+  float r = __builtin_amdgcn_rcpf(1.0f + e);      // 1 - s
+  float s_ = 1.0f - r;
+  float du = __builtin_fmaf(0.2140644488f, a2, 1.5957691216f);   // 2 c0 (1 + 3 c1 a^2)
+  return __builtin_fmaf(a * s_ * r, du, s_);
 }
 
 // ---- wave (64 lanes) and block reductions ------------------------------------------------------
@@ -143,6 +148,7 @@ struct FusedP {
   float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients are accumulated here (null otherwise)
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error
   float* Z; double* mse;
+  unsigned long long* dbg;   // diagnostic builds only (-DCORA_STAMPS)
 };
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
 int launch_chain(const FusedP& p, int store_h, hipStream_t st);

@@ -61,6 +61,7 @@ struct cora_ctx {
   float *xn1, *st1, *qkv, *att, *lse, *y, *xn2, *st2, *a;
   float *da, *dzn, *dy, *dO, *delta, *dqkv, *dxn;
   float *ua, *ub, *z, *stash = nullptr;
+  unsigned long long* dbg = nullptr;
   float* gscale = nullptr;   // [L] layer scale of the vode each block reads
   float* eta_dev = nullptr;  // [Tmax]
   double* energies = nullptr;  // [(Tmax+2), L+3]
@@ -304,6 +305,7 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.S_dy = c->dy; f.S_dqkv = c->dqkv;
   f.S_stash = c->stash;
   f.Z = c->z; f.mse = nullptr;
+  f.dbg = c->dbg;
 }
 
 // energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
@@ -549,6 +551,27 @@ int cora_destroy(cora_ctx* c) {
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
+  return 0;
+}
+
+// Diagnostic (stamps build): allocate / fetch the per-workgroup phase stamps of the fused kernel.
+extern "C" int cora_dbg_stamps(cora_ctx* c, unsigned long long* host, size_t n) {
+  if (!c) return -1;
+  size_t need = (size_t)(c->L + 1) * c->B * 16;
+  if (!c->dbg) {
+    void* v = nullptr;
+    HCHECK(hipMalloc(&v, need * 8));
+    HCHECK(hipMemset(v, 0, need * 8));
+    c->allocs.push_back(v);
+    c->dbg = (unsigned long long*)v;
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    return 0;
+  }
+  if (host && n == need) {
+    HCHECK(hipStreamSynchronize(c->st));
+    HCHECK(hipMemcpy(host, c->dbg, need * 8, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 

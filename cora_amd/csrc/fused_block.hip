@@ -244,6 +244,23 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
 //   MODE_CHAIN: x comes in registers (xio), forward only, the prediction u goes back in xio
 enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
 
+// Diagnostic build only (-DCORA_STAMPS): wave 0 of each workgroup records s_memtime at phase
+// boundaries into p.dbg[blockIdx.x * 16 + k].  Never compiled into the shipped library.
+#ifdef CORA_STAMPS
+#define STAMP(K)                                                                                   \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (MODE == MODE_INFER && p.dbg) {                                                             \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                 \
+      if (threadIdx.x == 0) p.dbg[(long long)blockIdx.x * 16 + (K)] = t_;                          \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define STAMP(K) do {} while (0)
+#endif
+
 template <int MODE>
 __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, int b, float* xio) {
   constexpr int D = 64, M = 256;
@@ -285,40 +302,42 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const float* ln2g = p.W + p.oLn2g + (long long)g * D;
   const float* ln2b = p.W + p.oLn2b + (long long)g * D;
 
-  // ---- weight tile pipeline: global -> registers (prefetch) -> LDS (double buffered) ------------
-  // Named registers + macros (not lambdas over an array: hipcc then keeps the staging registers in
-  // scratch and waits for every global load at once).  Thread t stages float4 #t, t+256, t+512, t+768
-  // of the 64x64 tile: row = f >> 4, 16-byte column = f & 15.
-  float4 sr0, sr1, sr2, sr3;
-  int cur = 1;
+  // ---- weight tile pipeline: global -> registers (prefetched TWO tiles ahead) -> LDS (double buffered)
+  // 24 tiles per block, even tiles use register set 0 / LDS buffer 0, odd tiles set 1 / buffer 1.
+  // Invariant when tile k is computed: tile k is in LDS buffer k&1, tile k+1 waits in register set
+  // (k+1)&1 and tile k+2 is in flight into set k&1.  Named registers + macros (not lambdas over an
+  // array: hipcc then keeps the staging registers in scratch).  Thread t stages float4 #t, t+256,
+  // t+512, t+768 of the 64x64 tile: row = f >> 4, 16-byte column = f & 15.
+  float4 sr00, sr01, sr02, sr03, sr10, sr11, sr12, sr13;
   const int srow = tid >> 4, scol = 4 * (tid & 15);
-#define PREFETCH(SRC, LDW)                                                                        \
+#define PREFETCH(S, SRC, LDW)                                                                     \
   do {                                                                                            \
     const float* s_ = (SRC) + (long long)srow * (LDW) + scol;                                     \
-    sr0 = *reinterpret_cast<const float4*>(s_);                                                   \
-    sr1 = *reinterpret_cast<const float4*>(s_ + 16LL * (LDW));                                    \
-    sr2 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                                    \
-    sr3 = *reinterpret_cast<const float4*>(s_ + 48LL * (LDW));                                    \
+    sr##S##0 = *reinterpret_cast<const float4*>(s_);                                              \
+    sr##S##1 = *reinterpret_cast<const float4*>(s_ + 16LL * (LDW));                               \
+    sr##S##2 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                               \
+    sr##S##3 = *reinterpret_cast<const float4*>(s_ + 48LL * (LDW));                               \
   } while (0)
-  // publish the prefetched tile into the other buffer.  One barrier per tile: the buffer being
-  // overwritten was last read two tiles ago, i.e. before the previous barrier.
-#define PUBLISH(TPTR)                                                                             \
+  // publish register set S into LDS buffer S.  One barrier per tile: the buffer being overwritten
+  // was last read two tiles ago, i.e. before the previous barrier.
+#define PUBLISH(S, TPTR)                                                                          \
   do {                                                                                            \
-    cur ^= 1;                                                                                     \
-    float* d_ = wbuf + cur * TILE + srow * LD + scol;                                             \
-    *reinterpret_cast<float4*>(d_) = sr0;                                                         \
-    *reinterpret_cast<float4*>(d_ + 16 * LD) = sr1;                                               \
-    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr2;                                               \
-    *reinterpret_cast<float4*>(d_ + 48 * LD) = sr3;                                               \
+    float* d_ = wbuf + S * TILE + srow * LD + scol;                                               \
+    *reinterpret_cast<float4*>(d_) = sr##S##0;                                                    \
+    *reinterpret_cast<float4*>(d_ + 16 * LD) = sr##S##1;                                          \
+    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr##S##2;                                          \
+    *reinterpret_cast<float4*>(d_ + 48 * LD) = sr##S##3;                                          \
     __syncthreads();                                                                              \
-    TPTR = wbuf + cur * TILE;                                                                     \
+    TPTR = wbuf + S * TILE;                                                                       \
   } while (0)
 
-  PREFETCH(Wqkv, D);
+  PREFETCH(0, Wqkv, D);            // tile 0: Wq
+  PREFETCH(1, Wqkv + 64 * D, D);   // tile 1: Wk
   const float* t;
   f32x4 acc[4];
   const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
 
+  STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], y[16];
   if (MODE == MODE_CHAIN) {
@@ -336,20 +355,22 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       ln_rowT(x, gm, bt, xh, xin);
       if (MODE == MODE_STORE) store_rowT(xin, p.S_xn1 + srow_g * D, grp);
     }
+    STAMP(1);
     float qf[16];
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
-      PUBLISH(t); PREFETCH(Wqkv + 64 * D, D);
+      PUBLISH(0, t); PREFETCH(0, Wqkv + 128 * D, D);   // -> tile 2: Wv
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
       if (MODE != MODE_CHAIN) store_rowT(qf, st_q, grp);
       float kf[16];
-      PUBLISH(t); PREFETCH(Wqkv + 128 * D, D);
+      PUBLISH(1, t); PREFETCH(1, Wo, D);               // -> tile 3: Wo
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
       store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
-      PUBLISH(t); PREFETCH(Wo, D);
+      PUBLISH(0, t); PREFETCH(0, W1, D);               // -> tile 4: W1[0]
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
       store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
     }
     __syncthreads();   // K, V of all 64 tokens visible
+    STAMP(2);
     // attention: S[key][q] -> softmax over keys -> O
     float of[16];
     {
@@ -371,7 +392,8 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
       if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
     }
-    PUBLISH(t); PREFETCH(W1, D);       // Wo
+    STAMP(3);
+    PUBLISH(1, t); PREFETCH(1, W2, M);   // Wo; -> tile 5: W2[:, 0]
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
@@ -386,12 +408,15 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       ln_rowT(y, gm, bt, xh, zn);
       if (MODE == MODE_STORE) store_rowT(zn, p.S_xn2 + srow_g * D, grp);
     }
+    STAMP(4);
     // a_mt = LN2(y) W1[mt]^T + b1 ; z += gelu(a_mt) W2[:, mt]^T   (row tile of W1, K-chunk of W2, interleaved)
     f32x4 zacc[4];
     zero4(zacc);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      PUBLISH(t); PREFETCH(W2 + mt * 64, M);
+      PUBLISH(0, t);                                        // tile 4+2mt: W1[mt]
+      if (mt < 3) PREFETCH(0, W1 + (mt + 1) * 64 * D, D);   // -> tile 6+2mt
+      else if (MODE != MODE_CHAIN) PREFETCH(0, W2T, D);     // -> tile 12: W2^T[0]
       float am[16];
       {
         float b1[16];
@@ -403,10 +428,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (MODE != MODE_CHAIN) store_rowT(am, st_a + 64 * mt, grp);
 #pragma unroll
       for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
-      PUBLISH(t);
-      if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D); else PREFETCH(W2T, D);
+      PUBLISH(1, t);                                        // tile 5+2mt: W2[:, mt]
+      if (mt < 3) PREFETCH(1, W2 + (mt + 1) * 64, M);       // -> tile 7+2mt
+      else if (MODE != MODE_CHAIN) PREFETCH(1, W1T, M);     // -> tile 13: W1^T[:, 0]
       gemm_tile(t, am, zacc, i, grp);
     }
+    STAMP(5);
     float z[16], b2[16];
     unpack(zacc, z);
     load_rowT(b2, p.W + p.ob2 + (long long)g * D, D, grp);
@@ -434,6 +461,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     if (MODE == MODE_STORE) colsum_atomic<4>(r, p.dW + p.ob2 + (long long)g * D, -1.f, i, grp);
   }
 
+  STAMP(6);
   // ---- backward (cotangent r) -----------------------------------------------------------------------
   // da_mt = (r W2)[mt] * gelu'(a_mt) ; dzn += da_mt W1[mt]   (row tile of W2^T, K-chunk of W1^T, interleaved)
   float dy[16];
@@ -442,7 +470,8 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     zero4(dacc);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      PUBLISH(t); PREFETCH(W1T + mt * 64, M);
+      PUBLISH(0, t);                                        // tile 12+2mt: W2^T[mt]
+      if (mt < 3) PREFETCH(0, W2T + (mt + 1) * 64 * D, D); else PREFETCH(0, WoT, D);   // -> tile 14+2mt / 20
       float am[16], dg[16];
       load_rowT(am, st_a + 64 * mt, M, grp);
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
@@ -452,10 +481,11 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
         store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
         colsum_atomic<4>(dg, p.dW + p.ob1 + (long long)g * M + 64 * mt, -1.f, i, grp);
       }
-      PUBLISH(t);
-      if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(WoT, D);
+      PUBLISH(1, t);                                        // tile 13+2mt: W1^T[:, mt]
+      if (mt < 3) PREFETCH(1, W1T + (mt + 1) * 64, M); else PREFETCH(1, WqkvT, 3 * D);   // -> tile 15+2mt / 21
       gemm_tile(t, dg, dacc, i, grp);
     }
+    STAMP(7);
     // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from the stashed y
     float dzn[16], gm[16], bt[16], xh[17], yv[16], tmp[16];
     unpack(dacc, dzn);
@@ -475,9 +505,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       colsum_atomic<4>(dzn, p.dW + p.oLn2g + (long long)g * D, -1.f, i, grp);
     }
   }
+  STAMP(8);
   {  // dO = dy Wo ; from here on r + dy is all that is needed of either
     float dof[16];
-    PUBLISH(t); PREFETCH(WqkvT, 3 * D);
+    PUBLISH(0, t); PREFETCH(0, WqkvT + 64, 3 * D);     // tile 20: Wo^T; -> tile 22
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
 #pragma unroll
     for (int k = 0; k < 16; ++k) r[k] += dy[k];
@@ -486,6 +517,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     float qf[16];
     load_rowT(qf, st_q, D, grp);
     store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
+    STAMP(9);
     // attention backward, pass A (own queries): dP, delta, dS, dQ
     float pf[16], dp[16];
     load_rowT(pf, st_p, D, grp);
@@ -502,6 +534,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     for (int k = 0; k < 16; ++k) dy[k] *= 0.125f;
   }
   __syncthreads();   // Q, dO rows and delta of all tokens visible
+  STAMP(10);
   // pass B (own keys): S, dP recomputed with the key on the lane; dV, dK
   float dk[16], dv[16];
   {
@@ -534,15 +567,16 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     store_rowT(dv, p.S_dqkv + srow_g * 3 * D + 2 * D, grp);
   }
   __syncthreads();     // Q / dO no longer read: the buffers go back to the weight pipeline
+  STAMP(11);
   {  // dxn = [dq | dk | dv] Wqkv (3 K-chunks of Wqkv^T), dx = r + dy + LN1^T(dxn)
-    cur = 1;
     zero4(acc);
-    PUBLISH(t); PREFETCH(WqkvT + 64, 3 * D);
+    PUBLISH(1, t); PREFETCH(1, WqkvT + 128, 3 * D);    // tile 21; -> tile 23
     gemm_tile(t, dy, acc, i, grp);
-    PUBLISH(t); PREFETCH(WqkvT + 128, 3 * D);
+    PUBLISH(0, t);                                     // tile 22
     gemm_tile(t, dk, acc, i, grp);
-    PUBLISH(t);
+    PUBLISH(1, t);                                     // tile 23
     gemm_tile(t, dv, acc, i, grp);
+    STAMP(12);
     float dxn[16], gm[16], bt[16], xh[17], xv[16], tmp[16];
     unpack(acc, dxn);
     load_rowT(xv, xrow, D, grp);          // LN1's normalised input is recomputed from x
@@ -560,6 +594,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
     for (int k = 0; k < 16; ++k) dk[k] += r[k];        // r holds r + dy
     store_rowT(dk, p.BP1 + (long long)g * nl + rowoff, grp);
+    STAMP(13);
   }
 }
 
