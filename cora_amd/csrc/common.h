@@ -117,6 +117,18 @@ struct UpdateP {
   int use_grad_norm; float grad_norm_target;
 };
 void launch_update(const UpdateP& p, hipStream_t st);
+// Fused path, pass 1 of the vode step: g_v = s_v (e_v + l1 sign(h_v) + 2 l2 h_v - bp_v) for vodes 1..L+1,
+// its sum of squares (8 slots per vode) and the vode energies 1/2 e^2 + l1 |h| + l2 h^2 (8 slots per vode).
+// bp and g may be the same array.  launch_update then applies clip + momentum SGD.
+struct VodeGradP {
+  const float* bp; const float* e; const float* h;   // [nlay, nl] each: J^T e, e and h of vodes 1..
+  float* g;                                          // [nlay, nl] out
+  const float* gscale; long long nl; int nlay;
+  float l1, l2;
+  double* sumsq;   // slots of vode 1 (vode 0's are filled by the edge path)
+  double* esum;    // slots of vode 1
+};
+void launch_vode_grad(const VodeGradP& p, hipStream_t st);
 // column sums: out[g*sOut + c] += alpha * sum_rows a[row, c] * (b ? b'[row, c] : 1), where
 // b' = b, or (b - mean[row]) * rstd[row] when stats ([rows,2]) is given
 void launch_colsum(const float* a, const float* b, const float* stats, float* out, long long sOut,
@@ -136,7 +148,9 @@ struct FusedP {
   const float* H1; float* E2; float* BP1; const float* W; const float* WT;
   long long oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2;
   long long tWqkv, tWo, tW1, tW2;
-  double* energy; int B; float l1, l2;
+  double* energy;   // STORE pass: per-vode energies accumulated here directly (null in the inference step)
+  double* esens;    // inference step: 8 slots for the sensory energy (the vode-step kernel derives the rest from e)
+  int B; float l1, l2;
   // edge layers (vode 0 / 1 and vode L+1 / sensory), one extra workgroup per image
   int L; float s0;
   const float* H0; const float* XP; const float* pos;
@@ -153,5 +167,3 @@ struct FusedP {
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
 int launch_chain(const FusedP& p, int store_h, hipStream_t st);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);
-void launch_grad_finish(float* gbp, const float* e, const float* h, const float* gscale, long long nl, int L,
-                        float l1, float l2, double* red, hipStream_t st);

@@ -20,7 +20,7 @@ thread_local std::string g_create_err;
 
 enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_FUSED, K_GRADFIN, K_COUNT };
 const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd",
-                                   "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "grad_finish"};
+                                   "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "vode_grad"};
 
 struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
 
@@ -65,7 +65,8 @@ struct cora_ctx {
   float* gscale = nullptr;   // [L] layer scale of the vode each block reads
   float* eta_dev = nullptr;  // [Tmax]
   double* energies = nullptr;  // [(Tmax+2), L+3]
-  double* sumsq = nullptr;     // [(Tmax+2), L+2]
+  double* sumsq = nullptr;     // [(Tmax+2), L+2, 8 slots]
+  double* esum = nullptr;      // [(Tmax+2), L+3, 8 slots]  energy slots of the fused inference step
   double* scal = nullptr;      // [0]=w-grad sumsq, [1]=mse sum
   float scale_l[64];
 
@@ -289,6 +290,23 @@ double block_step_flops(cora_ctx* c) {
   return (double)c->L * c->B * (48.0 * c->N * c->D * (double)c->D + 12.0 * c->N * (double)c->N * c->D);
 }
 
+// energy log row `slot` (L+3 doubles, index = vode) to the host.  Inference steps of the fused path
+// keep 8 partial sums per vode (no same-address atomics in the hot kernels); they are folded here.
+int energy_row(cora_ctx* c, int slot, double* en) {
+  const int L = c->L;
+  if (c->fused && slot < c->Tmax) {
+    std::vector<double> s8((size_t)(L + 3) * 8);
+    if (hipMemcpy(s8.data(), c->esum + (long long)slot * (L + 3) * 8, sizeof(double) * s8.size(), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (int v = 0; v < L + 3; ++v) {
+      double e = 0.0;
+      for (int k = 0; k < 8; ++k) e += s8[(size_t)v * 8 + k];
+      en[v] = e;
+    }
+    return 0;
+  }
+  return hipMemcpy(en, c->energies + (long long)slot * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+
 // parameter block of the fused kernels (pc_block_fused / pc_chain)
 void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */, double* ss /* sumsq row */) {
   const int L = c->L;
@@ -297,7 +315,7 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
   f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
   f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
-  f.energy = en ? en + 2 : nullptr; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
+  f.energy = en ? en + 2 : nullptr; f.esens = nullptr; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
   f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
   f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
   f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
@@ -327,22 +345,29 @@ int infer_step(cora_ctx* c, int t) {
   int rc = 0;
   double* ss = c->sumsq + (long long)t * (L + 2) * 8;
   if (c->fused) {
-    double* en = c->energies + (long long)t * (L + 3);
+    // fused kernel: e, J^T e, g_0 and the sensory energy ; vode_grad: g (in place over J^T e), its sums
+    // of squares and the other energies (8 slots each: no same-address atomics in the hot kernels)
+    double* es = c->esum + (long long)t * (L + 3) * 8;
     FusedP f;
-    fill_fused(c, f, en, ss);
+    fill_fused(c, f, nullptr, ss);
+    f.esens = es + (long long)(L + 2) * 8;
     {
       double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
       KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl);
       if (launch_fused_block(f, L, 0, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     }
+    VodeGradP v; memset(&v, 0, sizeof v);
+    v.bp = vode_ptr(c, c->Gs, 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hs, 1); v.g = vode_ptr(c, c->Gs, 1);
+    v.gscale = c->gscale; v.nl = c->nl; v.nlay = L + 1; v.l1 = c->cfg.l1; v.l2 = c->cfg.l2;
+    v.sumsq = ss + 8; v.esum = es + 8;
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
-    launch_grad_finish(vode_ptr(c, c->Gs, 1), err_ptr(c, 1), vode_ptr(c, c->Hs, 1), c->gscale, c->nl, L + 1, c->cfg.l1, c->cfg.l2, ss + 8, c->st);
+    launch_vode_grad(v, c->st);
   } else {
     int rc0 = errors_pass(c, t);
     if (rc0) return rc0;
   }
-  // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   if (!c->fused) {
+  // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
   p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
@@ -379,6 +404,7 @@ int enqueue_infer(cora_ctx* c, int T) {
   // guards this.
   launch_zero(c->energies, ((sizeof(double) * (size_t)T * (L + 3)) + 15) / 16 * 16, c->st);
   launch_zero(c->sumsq, sizeof(double) * (size_t)T * (L + 2) * 8, c->st);
+  if (c->fused) launch_zero(c->esum, sizeof(double) * (size_t)T * (L + 3) * 8, c->st);
   launch_zero(c->Ms, sizeof(float) * (size_t)c->nV, c->st);   // optim_h.init, :414
   for (int t = 0; t < T; ++t) {
     int rc = infer_step(c, t);
@@ -515,10 +541,11 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
   DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
   if (c->fused) DA(c->stash, rows * 3 * D);
-  DA(c->gscale, 64); DA(c->eta_dev, c->Tmax);
+  DA(c->gscale, 64); DA(c->eta_dev, c->Tmax + 1);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
+  DA(tmp, 16LL * (c->Tmax + 2) * (L + 3)); c->esum = (double*)tmp;
   DA(tmp, 8); c->scal = (double*)tmp;
 #undef DA
   // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
@@ -765,7 +792,7 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     out->infer_ms = ms;
     std::vector<double> en((size_t)c->L + 3);
-    HCHECK(hipMemcpy(en.data(), c->energies + (long long)(T - 1) * (c->L + 3), sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+    if (energy_row(c, T - 1, en.data())) FAIL(-2, "energy read-back failed");
     double tot = 0.0;
     for (double v : en) tot += v;
     out->final_h_energy = tot;
@@ -904,7 +931,8 @@ int cora_get_energies(cora_ctx* c, int T, double* total, double* per_layer) {
   const int W = c->L + 3;
   std::vector<double> en((size_t)T * W);
   HCHECK(hipStreamSynchronize(c->st));
-  HCHECK(hipMemcpy(en.data(), c->energies, sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+  for (int t = 0; t < T; ++t)
+    if (energy_row(c, t, en.data() + (size_t)t * W)) FAIL(-2, "energy read-back failed");
   for (int t = 0; t < T; ++t) {
     double s = 0.0;
     for (int l = 0; l < W; ++l) s += en[(size_t)t * W + l];
@@ -968,12 +996,14 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   HCHECK(hipMemcpy(c->eta_dev, &eta0, sizeof(float), hipMemcpyHostToDevice));
   HCHECK(hipMemsetAsync(c->energies, 0, sizeof(double) * (c->L + 3), c->st));
   HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (c->L + 2) * 8, c->st));
-  infer_step(c, 0);   // warm
+  HCHECK(hipMemsetAsync(c->esum, 0, sizeof(double) * (c->L + 3) * 8, c->st));
+  const int tp = 0;
+  infer_step(c, tp);   // warm
   HCHECK(hipStreamSynchronize(c->st));
   c->prof = true; c->recs.clear();
   const int reps = 5;
   int rc = 0;
-  for (int i = 0; i < reps && !rc; ++i) rc = infer_step(c, 0);
+  for (int i = 0; i < reps && !rc; ++i) rc = infer_step(c, tp);
   c->prof = false;
   HCHECK(hipStreamSynchronize(c->st));
   for (int k = 0; k < K_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; snprintf(names + 32 * k, 32, "%s", kKindNames[k]); }

@@ -30,19 +30,34 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // (weights, K, Q, V or dO rows; row stride LDT) -> acc[ot][reg'] = Y[row r][16 ot + 4 grp + reg']
 template <int NOT, int NCT, int LDT>
 __device__ __forceinline__ void gemm_tile_g(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
+  // A fragments are fetched one column tile ahead of the MFMAs that use them; the sched_group_barrier
+  // pairs (1 LDS read : 4 MFMA) keep the compiler from sinking the reads back next to their uses,
+  // which left the matrix pipe idle for a full LDS latency in front of every 4-MFMA run.
+  float4 a[2][NOT];
+#pragma unroll
+  for (int ot = 0; ot < NOT; ++ot) a[0][ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 4 * grp]);
+  __builtin_amdgcn_sched_group_barrier(0x100, NOT, 0);
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    float4 a[NOT];
+    const int cb = ct & 1;
+    if (ct + 1 < NCT) {
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 16 * ct + 4 * grp]);
+      for (int ot = 0; ot < NOT; ++ot)
+        a[cb ^ 1][ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 16 * (ct + 1) + 4 * grp]);
+    }
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * ct + 0], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].x, xf[4 * ct + 0], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * ct + 1], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].y, xf[4 * ct + 1], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * ct + 2], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].z, xf[4 * ct + 2], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * ct + 3], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].w, xf[4 * ct + 3], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one ds_read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
+    }
   }
 }
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
@@ -143,7 +158,7 @@ __device__ __forceinline__ void ln_bwd_rowT(const float* dout, const float* gam,
 
 // ---- edge layers of one image: vode 0 <-> vode 1 (patch projection) and vode L+1 <-> sensory ------
 //   e_1 = h_1 - (h_0 Wp^T + bp + pos)          g_0 = -s_0 e_1 Wp              (vode 0 has no own energy)
-//   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by grad_finish)
+//   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by vode_grad_kernel)
 // (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153)
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int rows, int cols, int ldt, int tid) {
   const int c4n = cols / 4;
@@ -166,6 +181,7 @@ __device__ __forceinline__ void store_rowT_n(const float* f, float* base, int gr
   for (int ct = 0; ct < NCT; ++ct)
     *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
 }
+
 
 __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   constexpr int D = 64, P = 48, LP = 52;   // P = 48 patch dim; LP = padded stride of 48-wide tiles
@@ -203,7 +219,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
     store_rowT_n<4>(e1, p.E1 + tok * D, grp);
     if (p.dW) colsum_atomic<4>(e1, p.dW + p.obp, -1.f, i, grp);
     double tot = wave_sum_d((double)en);
-    if (lane == 0) atomicAdd(&p.energy[-1], tot);            // energy[] points at vode 2; vode 1 is [-1]
+    if (p.energy && lane == 0) atomicAdd(&p.energy[-1], tot);   // energy[] points at vode 2; vode 1 is [-1]
   }
   {
     zero4(acc); gemm_tile_g<3, 4, LD>(sWpT, e1, acc, i, grp);
@@ -230,7 +246,10 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
     store_rowT_n<3>(ei, p.EIMG + tok * P, grp);
     if (p.dW) colsum_atomic<3>(ei, p.dW + p.obout, -1.f, i, grp);
     double tot = wave_sum_d((double)en);
-    if (lane == 0) atomicAdd(&p.energy[p.L], tot);           // vode L+2
+    if (lane == 0) {                                         // vode L+2 (sensory)
+      if (p.energy) atomicAdd(&p.energy[p.L], tot);
+      else atomicAdd(&p.esens[(b * 4 + w) & 7], tot);
+    }
     zero4(acc); gemm_tile_g<4, 3, LP>(sWoT, ei, acc, i, grp);
     float bpl[16];
     unpack(acc, bpl);
@@ -247,10 +266,16 @@ enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
 // Diagnostic build only (-DCORA_STAMPS): wave 0 of each workgroup records s_memtime at phase
 // boundaries into p.dbg[blockIdx.x * 16 + k].  Never compiled into the shipped library.
 #ifdef CORA_STAMPS
-#define STAMP(K)                                                                                   \
+#define STAMP(K) STAMP_IF(CORA_STAMPS == 1 || (K) <= 1, K)
+#if CORA_STAMPS == 2
+#define SUB(K) STAMP_IF(1, K)      /* -DCORA_STAMPS=2: zoom into the first two MLP-backward tile pairs */
+#else
+#define SUB(K) do {} while (0)
+#endif
+#define STAMP_IF(COND, K)                                                                          \
   do {                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    if (MODE == MODE_INFER && p.dbg) {                                                             \
+    if ((COND) && MODE == MODE_INFER && p.dbg) {                                                             \
       unsigned long long t_;                                                                       \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                 \
       if (threadIdx.x == 0) p.dbg[(long long)blockIdx.x * 16 + (K)] = t_;                          \
@@ -259,7 +284,9 @@ enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
   } while (0)
 #else
 #define STAMP(K) do {} while (0)
+#define SUB(K) do {} while (0)
 #endif
+
 
 template <int MODE>
 __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, int b, float* xio) {
@@ -278,8 +305,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const int i = lane & 15, grp = lane >> 4;
   const long long nl = (long long)p.B * 64 * D;
   const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;   // this lane's token row
-  const float* xrow = p.H1 + (long long)g * nl + rowoff;
-  const float* hnext = p.H1 + (long long)(g + 1) * nl + rowoff;
+  const long long voff = (long long)g * nl + rowoff;               // into the vode-1-based arenas
+  const float* xrow = p.H1 + voff;
+  const float* hnext = p.H1 + voff + nl;
   const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
   // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
   // in the forward and only needed again in the backward (q, P, y, the MLP pre-activation a) are
@@ -359,17 +387,26 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     float qf[16];
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
       PUBLISH(0, t); PREFETCH(0, Wqkv + 128 * D, D);   // -> tile 2: Wv
+     
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
+     
       if (MODE != MODE_CHAIN) store_rowT(qf, st_q, grp);
       float kf[16];
+     
       PUBLISH(1, t); PREFETCH(1, Wo, D);               // -> tile 3: Wo
+     
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
+     
       store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
+     
       PUBLISH(0, t); PREFETCH(0, W1, D);               // -> tile 4: W1[0]
+     
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
+     
       store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
     }
     __syncthreads();   // K, V of all 64 tokens visible
+   
     STAMP(2);
     // attention: S[key][q] -> softmax over keys -> O
     float of[16];
@@ -457,7 +494,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     }
     store_rowT(r, p.E2 + (long long)g * nl + rowoff, grp);
     double tot = wave_sum_d((double)en);
-    if (lane == 0) atomicAdd(&p.energy[g], tot);
+    if (MODE == MODE_STORE && lane == 0) atomicAdd(&p.energy[g], tot);
     if (MODE == MODE_STORE) colsum_atomic<4>(r, p.dW + p.ob2 + (long long)g * D, -1.f, i, grp);
   }
 
@@ -470,10 +507,13 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     zero4(dacc);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+      if (mt < 2) SUB(2 + 6 * mt);
       PUBLISH(0, t);                                        // tile 12+2mt: W2^T[mt]
+      if (mt < 2) SUB(3 + 6 * mt);
       if (mt < 3) PREFETCH(0, W2T + (mt + 1) * 64 * D, D); else PREFETCH(0, WoT, D);   // -> tile 14+2mt / 20
       float am[16], dg[16];
       load_rowT(am, st_a + 64 * mt, M, grp);
+      if (mt < 2) SUB(4 + 6 * mt);
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
 #pragma unroll
       for (int k = 0; k < 16; ++k) dg[k] *= cora_gelu_grad(am[k]);
@@ -481,9 +521,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
         store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
         colsum_atomic<4>(dg, p.dW + p.ob1 + (long long)g * M + 64 * mt, -1.f, i, grp);
       }
+      if (mt < 2) SUB(5 + 6 * mt);
       PUBLISH(1, t);                                        // tile 13+2mt: W1^T[:, mt]
+      if (mt < 2) SUB(6 + 6 * mt);
       if (mt < 3) PREFETCH(1, W1T + (mt + 1) * 64, M); else PREFETCH(1, WqkvT, 3 * D);   // -> tile 15+2mt / 21
       gemm_tile(t, dg, dacc, i, grp);
+      if (mt < 2) SUB(7 + 6 * mt);
     }
     STAMP(7);
     // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from the stashed y
@@ -710,38 +753,4 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st) {
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, groups);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, src, dst, rows, cols);
-}
-
-// ---- g_l = s_l * (e_l + l1 sign(h_l) + 2 l2 h_l - bp_l) in place over bp, layers 1..L, + sum of squares ----
-__global__ __launch_bounds__(256) void grad_finish_kernel(float* __restrict__ gbp, const float* __restrict__ e,
-                                                          const float* __restrict__ h, const float* __restrict__ gscale,
-                                                          long long nl4, float l1, float l2, double* __restrict__ red) {
-  __shared__ double sh[4];
-  const int layer = blockIdx.y;
-  const float s = gscale[layer];
-  const long long base = (long long)layer * nl4;
-  double acc = 0.0;
-  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nl4; k += (long long)gridDim.x * blockDim.x) {
-    float4 bp = reinterpret_cast<const float4*>(gbp)[base + k];
-    float4 ev = reinterpret_cast<const float4*>(e)[base + k];
-    float o[4] = {ev.x, ev.y, ev.z, ev.w};
-    if (l1 != 0.f || l2 != 0.f) {
-      float4 hv = reinterpret_cast<const float4*>(h)[base + k];
-      float hh[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += l1 * ((hh[j] > 0.f) ? 1.f : ((hh[j] < 0.f) ? -1.f : 0.f)) + 2.f * l2 * hh[j];
-    }
-    float4 gv = make_float4(s * (o[0] - bp.x), s * (o[1] - bp.y), s * (o[2] - bp.z), s * (o[3] - bp.w));
-    reinterpret_cast<float4*>(gbp)[base + k] = gv;
-    acc += (double)gv.x * gv.x + (double)gv.y * gv.y + (double)gv.z * gv.z + (double)gv.w * gv.w;
-  }
-  double tot = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(&red[layer * 8 + (blockIdx.x & 7)], tot);
-}
-void launch_grad_finish(float* gbp, const float* e, const float* h, const float* gscale, long long nl, int L,
-                        float l1, float l2, double* red, hipStream_t st) {
-  long long nl4 = nl / 4;
-  long long bx = (nl4 + 255) / 256;
-  if (bx > 512) bx = 512;
-  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)bx, L), dim3(256), 0, st, gbp, e, h, gscale, nl4, l1, l2, red);
 }

@@ -249,6 +249,51 @@ void launch_update(const UpdateP& p, hipStream_t st) {
   hipLaunchKernelGGL(update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
 }
 
+// ---- fused path, pass 1 of the vode step (see VodeGradP) ---------------------------------------------
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
+  __shared__ double sh[4];
+  const int v = blockIdx.y;
+  const float s = p.gscale[v];
+  const long long nl4 = p.nl / 4;
+  const long long base = (long long)v * nl4;
+  const bool reg = (p.l1 != 0.f || p.l2 != 0.f);
+  double ss = 0.0;
+  float en = 0.f;
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nl4; k += (long long)gridDim.x * blockDim.x) {
+    float4 bp4 = reinterpret_cast<const float4*>(p.bp)[base + k];
+    float4 e4 = reinterpret_cast<const float4*>(p.e)[base + k];
+    float bp[4] = {bp4.x, bp4.y, bp4.z, bp4.w}, e[4] = {e4.x, e4.y, e4.z, e4.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = e[j]; en += 0.5f * e[j] * e[j]; }
+    if (reg) {
+      float4 h4 = reinterpret_cast<const float4*>(p.h)[base + k];
+      float h[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] += p.l1 * sgnf(h[j]) + 2.f * p.l2 * h[j];
+        en += p.l1 * fabsf(h[j]) + p.l2 * h[j] * h[j];
+      }
+    }
+    float4 gv = make_float4(s * (o[0] - bp[0]), s * (o[1] - bp[1]), s * (o[2] - bp[2]), s * (o[3] - bp[3]));
+    reinterpret_cast<float4*>(p.g)[base + k] = gv;
+    ss += (double)gv.x * gv.x + (double)gv.y * gv.y + (double)gv.z * gv.z + (double)gv.w * gv.w;
+  }
+  double tot = block_sum_256(ss, sh);
+  if (threadIdx.x == 0) atomicAdd(&p.sumsq[v * 8 + (blockIdx.x & 7)], tot);
+  __syncthreads();
+  tot = block_sum_256((double)en, sh);
+  if (threadIdx.x == 0) atomicAdd(&p.esum[v * 8 + (blockIdx.x & 7)], tot);
+}
+void launch_vode_grad(const VodeGradP& p, hipStream_t st) {
+  long long nl4 = p.nl / 4;
+  long long bx = (nl4 + 255) / 256;
+  if (bx > 512) bx = 512;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(vode_grad_kernel, dim3((unsigned)bx, p.nlay), dim3(256), 0, st, p);
+}
+
 // ---- column sums (bias / LayerNorm parameter gradients) ------------------------------------------
 // grid: (ceil(cols/64), row_chunks, groups); block 256 = 4 row lanes x 64 columns
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,

@@ -1,6 +1,5 @@
-"""Diagnostic: per-phase s_memtime breakdown of pc_block_fused (stamps build).  Usage:
-   CORA_HIP_LIB=cora_amd/libcora_hip_stamps.so CORA_NO_GRAPH=1 python scripts/stamps.py B"""
-import ctypes as C, sys, os
+"""Diagnostic: zoom stamps (-DCORA_STAMPS=2) over the three QKV tiles."""
+import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, ".")
 import cora_amd as ca
@@ -19,14 +18,10 @@ ca.train_on_batch(3, x, model=model, optim_w=ow, optim_h=oh)
 L = 6
 n = (L + 1) * B * 16
 st = np.zeros(n, dtype=np.uint64)
-# the wgrad pass (MODE_STORE) does not stamp, so these are from the last inference step
 lib.cora_dbg_stamps(model._ctx, st.ctypes.data_as(C.c_void_p), n)
 st = st.reshape(-1, 16)[: L * B, :14].astype(np.int64)
 d = np.diff(st, axis=1)
-names = ["LN1", "QKV(3 tiles)", "attn fwd", "Wo+LN2", "MLP fwd(8 tiles)", "err+energy", "MLP bwd(8)", "LN2 bwd", "dO tile", "passA", "passB", "dxn(3 tiles)", "LN1 bwd"]
-tot = (st[:, 13] - st[:, 0])
-print("B", B, "WGs", len(tot), "mean total cycles(100MHz ticks?)", tot.mean(), "min", tot.min(), "max", tot.max())
-for k, nm in enumerate(names):
-    print(f"  {nm:20s} mean {d[:, k].mean():9.0f}  ({100 * d[:, k].mean() / tot.mean():5.1f} %)")
-span = st[:, 13].max() - st[:, 0].min()
-print("kernel span", span)
+names = ["(fwd..)", "publish W2T", "prefetch+am load issue", "gemm+gelugrad", "publish W1T", "prefetch+gemm (async)"] * 2
+d = d[:, 1:]
+for k in range(12):
+    print(f"  {names[k]:24s} mean {d[:, k].mean():9.0f}  min {d[:, k].min():7d} max {d[:, k].max():7d}")
