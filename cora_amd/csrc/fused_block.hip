@@ -30,34 +30,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // (weights, K, Q, V or dO rows; row stride LDT) -> acc[ot][reg'] = Y[row r][16 ot + 4 grp + reg']
 template <int NOT, int NCT, int LDT>
 __device__ __forceinline__ void gemm_tile_g(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
-  // A fragments are fetched one column tile ahead of the MFMAs that use them; the sched_group_barrier
-  // pairs (1 LDS read : 4 MFMA) keep the compiler from sinking the reads back next to their uses,
-  // which left the matrix pipe idle for a full LDS latency in front of every 4-MFMA run.
-  float4 a[2][NOT];
-#pragma unroll
-  for (int ot = 0; ot < NOT; ++ot) a[0][ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 4 * grp]);
-  __builtin_amdgcn_sched_group_barrier(0x100, NOT, 0);
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    const int cb = ct & 1;
-    if (ct + 1 < NCT) {
+    float4 a[NOT];
 #pragma unroll
-      for (int ot = 0; ot < NOT; ++ot)
-        a[cb ^ 1][ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 16 * (ct + 1) + 4 * grp]);
-    }
+    for (int ot = 0; ot < NOT; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LDT + 16 * ct + 4 * grp]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].x, xf[4 * ct + 0], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * ct + 0], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].y, xf[4 * ct + 1], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * ct + 1], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].z, xf[4 * ct + 2], acc[ot]);
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * ct + 2], acc[ot]);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[cb][ot].w, xf[4 * ct + 3], acc[ot]);
-#pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one ds_read
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
-    }
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * ct + 3], acc[ot]);
   }
 }
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp) {
@@ -330,37 +315,36 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const float* ln2g = p.W + p.oLn2g + (long long)g * D;
   const float* ln2b = p.W + p.oLn2b + (long long)g * D;
 
-  // ---- weight tile pipeline: global -> registers (prefetched TWO tiles ahead) -> LDS (double buffered)
-  // 24 tiles per block, even tiles use register set 0 / LDS buffer 0, odd tiles set 1 / buffer 1.
-  // Invariant when tile k is computed: tile k is in LDS buffer k&1, tile k+1 waits in register set
-  // (k+1)&1 and tile k+2 is in flight into set k&1.  Named registers + macros (not lambdas over an
+  // ---- weight tile pipeline: global -> registers (prefetched one tile ahead) -> LDS (double buffered)
+  // 24 tiles per block, tile k goes to LDS buffer k&1.  While tile k is computed, tile k+1 is in
+  // flight into the staging registers (a second staging set, two tiles ahead, bought nothing and
+  // cost the 16 registers that now hold part of the MLP pre-activation).  Named registers + macros (not lambdas over an
   // array: hipcc then keeps the staging registers in scratch).  Thread t stages float4 #t, t+256,
   // t+512, t+768 of the 64x64 tile: row = f >> 4, 16-byte column = f & 15.
-  float4 sr00, sr01, sr02, sr03, sr10, sr11, sr12, sr13;
+  float4 sr0, sr1, sr2, sr3;
   const int srow = tid >> 4, scol = 4 * (tid & 15);
-#define PREFETCH(S, SRC, LDW)                                                                     \
+#define PREFETCH(SRC, LDW)                                                                        \
   do {                                                                                            \
     const float* s_ = (SRC) + (long long)srow * (LDW) + scol;                                     \
-    sr##S##0 = *reinterpret_cast<const float4*>(s_);                                              \
-    sr##S##1 = *reinterpret_cast<const float4*>(s_ + 16LL * (LDW));                               \
-    sr##S##2 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                               \
-    sr##S##3 = *reinterpret_cast<const float4*>(s_ + 48LL * (LDW));                               \
+    sr0 = *reinterpret_cast<const float4*>(s_);                                                   \
+    sr1 = *reinterpret_cast<const float4*>(s_ + 16LL * (LDW));                                    \
+    sr2 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                                    \
+    sr3 = *reinterpret_cast<const float4*>(s_ + 48LL * (LDW));                                    \
   } while (0)
-  // publish register set S into LDS buffer S.  One barrier per tile: the buffer being overwritten
+  // publish the staged tile into LDS buffer S.  One barrier per tile: the buffer being overwritten
   // was last read two tiles ago, i.e. before the previous barrier.
 #define PUBLISH(S, TPTR)                                                                          \
   do {                                                                                            \
     float* d_ = wbuf + S * TILE + srow * LD + scol;                                               \
-    *reinterpret_cast<float4*>(d_) = sr##S##0;                                                    \
-    *reinterpret_cast<float4*>(d_ + 16 * LD) = sr##S##1;                                          \
-    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr##S##2;                                          \
-    *reinterpret_cast<float4*>(d_ + 48 * LD) = sr##S##3;                                          \
+    *reinterpret_cast<float4*>(d_) = sr0;                                                         \
+    *reinterpret_cast<float4*>(d_ + 16 * LD) = sr1;                                               \
+    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr2;                                               \
+    *reinterpret_cast<float4*>(d_ + 48 * LD) = sr3;                                               \
     __syncthreads();                                                                              \
     TPTR = wbuf + S * TILE;                                                                       \
   } while (0)
 
-  PREFETCH(0, Wqkv, D);            // tile 0: Wq
-  PREFETCH(1, Wqkv + 64 * D, D);   // tile 1: Wk
+  PREFETCH(Wqkv, D);               // tile 0: Wq
   const float* t;
   f32x4 acc[4];
   const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
@@ -368,6 +352,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], y[16];
+  // MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
+  // the backward; the STORE pass writes it to HBM anyway (weight-gradient GEMM operand) and reloads it.
+  float a_keep[MODE == MODE_INFER ? 64 : 1];
   if (MODE == MODE_CHAIN) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = xio[k];
@@ -386,20 +373,20 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     STAMP(1);
     float qf[16];
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
-      PUBLISH(0, t); PREFETCH(0, Wqkv + 128 * D, D);   // -> tile 2: Wv
+      PUBLISH(0, t); PREFETCH(Wqkv + 64 * D, D);    // -> tile 1: Wk
      
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
      
       if (MODE != MODE_CHAIN) store_rowT(qf, st_q, grp);
       float kf[16];
      
-      PUBLISH(1, t); PREFETCH(1, Wo, D);               // -> tile 3: Wo
+      PUBLISH(1, t); PREFETCH(Wqkv + 128 * D, D);   // -> tile 2: Wv
      
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
      
       store_rowT(kf, &bufK[(16 * w + i) * LD], grp);
      
-      PUBLISH(0, t); PREFETCH(0, W1, D);               // -> tile 4: W1[0]
+      PUBLISH(0, t); PREFETCH(Wo, D);               // -> tile 3: Wo
      
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
      
@@ -430,7 +417,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
     }
     STAMP(3);
-    PUBLISH(1, t); PREFETCH(1, W2, M);   // Wo; -> tile 5: W2[:, 0]
+    PUBLISH(1, t); PREFETCH(W1, D);   // Wo; -> tile 4: W1[0]
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
@@ -452,8 +439,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       PUBLISH(0, t);                                        // tile 4+2mt: W1[mt]
-      if (mt < 3) PREFETCH(0, W1 + (mt + 1) * 64 * D, D);   // -> tile 6+2mt
-      else if (MODE != MODE_CHAIN) PREFETCH(0, W2T, D);     // -> tile 12: W2^T[0]
+      PREFETCH(W2 + mt * 64, M);                            // -> tile 5+2mt: W2[:, mt]
       float am[16];
       {
         float b1[16];
@@ -462,18 +448,32 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] += b1[k];
       }
-      if (MODE != MODE_CHAIN) store_rowT(am, st_a + 64 * mt, grp);
+      if (MODE == MODE_STORE) store_rowT(am, st_a + 64 * mt, grp);
+      if (MODE == MODE_INFER) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a_keep[16 * mt + k] = am[k];
+      }
 #pragma unroll
       for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
       PUBLISH(1, t);                                        // tile 5+2mt: W2[:, mt]
-      if (mt < 3) PREFETCH(1, W2 + (mt + 1) * 64, M);       // -> tile 7+2mt
-      else if (MODE != MODE_CHAIN) PREFETCH(1, W1T, M);     // -> tile 13: W1^T[:, 0]
+      if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D);      // -> tile 6+2mt
+      else if (MODE != MODE_CHAIN) PREFETCH(W2T, D);        // -> tile 12: W2^T[0]
       gemm_tile(t, am, zacc, i, grp);
     }
     STAMP(5);
     float z[16], b2[16];
     unpack(zacc, z);
     load_rowT(b2, p.W + p.ob2 + (long long)g * D, D, grp);
+    if (MODE == MODE_INFER) {
+      // x and y were dropped across the MLP loop to make room for a_keep: fetch them again (y from
+      // the stash it was parked in; the pointers are laundered so the compiler cannot keep the
+      // stored values live in registers instead)
+      const float* xp_ = xrow;
+      const float* yp_ = st_y;
+      asm volatile("" : "+v"(xp_), "+v"(yp_));
+      load_rowT(x, xp_, D, grp);
+      load_rowT(y, yp_, D, grp);
+    }
     if (MODE == MODE_CHAIN) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) xio[k] = x[k] + y[k] + z[k] + b2[k];
@@ -510,9 +510,14 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (mt < 2) SUB(2 + 6 * mt);
       PUBLISH(0, t);                                        // tile 12+2mt: W2^T[mt]
       if (mt < 2) SUB(3 + 6 * mt);
-      if (mt < 3) PREFETCH(0, W2T + (mt + 1) * 64 * D, D); else PREFETCH(0, WoT, D);   // -> tile 14+2mt / 20
+      PREFETCH(W1T + mt * 64, M);                           // -> tile 13+2mt: W1^T[:, mt]
       float am[16], dg[16];
-      load_rowT(am, st_a + 64 * mt, M, grp);
+      if (MODE == MODE_INFER) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) am[k] = a_keep[16 * mt + k];
+      } else {
+        load_rowT(am, st_a + 64 * mt, M, grp);
+      }
       if (mt < 2) SUB(4 + 6 * mt);
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
 #pragma unroll
@@ -524,7 +529,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (mt < 2) SUB(5 + 6 * mt);
       PUBLISH(1, t);                                        // tile 13+2mt: W1^T[:, mt]
       if (mt < 2) SUB(6 + 6 * mt);
-      if (mt < 3) PREFETCH(1, W1T + (mt + 1) * 64, M); else PREFETCH(1, WqkvT, 3 * D);   // -> tile 15+2mt / 21
+      if (mt < 3) PREFETCH(W2T + (mt + 1) * 64 * D, D); else PREFETCH(WoT, D);   // -> tile 14+2mt / 20
       gemm_tile(t, dg, dacc, i, grp);
       if (mt < 2) SUB(7 + 6 * mt);
     }
@@ -551,7 +556,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(8);
   {  // dO = dy Wo ; from here on r + dy is all that is needed of either
     float dof[16];
-    PUBLISH(0, t); PREFETCH(0, WqkvT + 64, 3 * D);     // tile 20: Wo^T; -> tile 22
+    PUBLISH(0, t); PREFETCH(WqkvT, 3 * D);          // tile 20: Wo^T; -> tile 21 (waits in registers through the attention backward)
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
 #pragma unroll
     for (int k = 0; k < 16; ++k) r[k] += dy[k];
@@ -613,9 +618,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(11);
   {  // dxn = [dq | dk | dv] Wqkv (3 K-chunks of Wqkv^T), dx = r + dy + LN1^T(dxn)
     zero4(acc);
-    PUBLISH(1, t); PREFETCH(1, WqkvT + 128, 3 * D);    // tile 21; -> tile 23
+    PUBLISH(1, t); PREFETCH(WqkvT + 64, 3 * D);     // tile 21; -> tile 22
     gemm_tile(t, dy, acc, i, grp);
-    PUBLISH(0, t);                                     // tile 22
+    PUBLISH(0, t); PREFETCH(WqkvT + 128, 3 * D);    // tile 22; -> tile 23
     gemm_tile(t, dk, acc, i, grp);
     PUBLISH(1, t);                                     // tile 23
     gemm_tile(t, dv, acc, i, grp);

@@ -259,26 +259,40 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
   const long long nl4 = p.nl / 4;
   const long long base = (long long)v * nl4;
   const bool reg = (p.l1 != 0.f || p.l2 != 0.f);
+  const float4* __restrict__ bpp = reinterpret_cast<const float4*>(p.bp) + base;
+  const float4* __restrict__ ep = reinterpret_cast<const float4*>(p.e) + base;
+  const float4* __restrict__ hp = reinterpret_cast<const float4*>(p.h) + base;
+  float4* gp = reinterpret_cast<float4*>(p.g) + base;
   double ss = 0.0;
   float en = 0.f;
-  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nl4; k += (long long)gridDim.x * blockDim.x) {
-    float4 bp4 = reinterpret_cast<const float4*>(p.bp)[base + k];
-    float4 e4 = reinterpret_cast<const float4*>(p.e)[base + k];
-    float bp[4] = {bp4.x, bp4.y, bp4.z, bp4.w}, e[4] = {e4.x, e4.y, e4.z, e4.w}, o[4];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  // two independent float4 streams per thread and iteration: enough loads in flight to run at
+  // the memory rate with the 8 waves per SIMD this kernel gets
+  for (long long k0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; k0 < nl4; k0 += 2 * stride) {
+    const long long k1 = k0 + stride;
+    const bool two = k1 < nl4;
+    float4 bq[2], eq[2], hq[2];
+    bq[0] = bpp[k0]; eq[0] = ep[k0];
+    if (two) { bq[1] = bpp[k1]; eq[1] = ep[k1]; }
+    if (reg) { hq[0] = hp[k0]; if (two) hq[1] = hp[k1]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { o[j] = e[j]; en += 0.5f * e[j] * e[j]; }
-    if (reg) {
-      float4 h4 = reinterpret_cast<const float4*>(p.h)[base + k];
-      float h[4] = {h4.x, h4.y, h4.z, h4.w};
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float bp[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w}, e[4] = {eq[u].x, eq[u].y, eq[u].z, eq[u].w}, o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] += p.l1 * sgnf(h[j]) + 2.f * p.l2 * h[j];
-        en += p.l1 * fabsf(h[j]) + p.l2 * h[j] * h[j];
+      for (int j = 0; j < 4; ++j) { o[j] = e[j]; en += 0.5f * e[j] * e[j]; }
+      if (reg) {
+        float h[4] = {hq[u].x, hq[u].y, hq[u].z, hq[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] += p.l1 * sgnf(h[j]) + 2.f * p.l2 * h[j];
+          en += p.l1 * fabsf(h[j]) + p.l2 * h[j] * h[j];
+        }
       }
+      float4 gv = make_float4(s * (o[0] - bp[0]), s * (o[1] - bp[1]), s * (o[2] - bp[2]), s * (o[3] - bp[3]));
+      gp[u == 0 ? k0 : k1] = gv;
+      ss += (double)(gv.x * gv.x + gv.y * gv.y) + (double)(gv.z * gv.z + gv.w * gv.w);
     }
-    float4 gv = make_float4(s * (o[0] - bp[0]), s * (o[1] - bp[1]), s * (o[2] - bp[2]), s * (o[3] - bp[3]));
-    reinterpret_cast<float4*>(p.g)[base + k] = gv;
-    ss += (double)gv.x * gv.x + (double)gv.y * gv.y + (double)gv.z * gv.z + (double)gv.w * gv.w;
   }
   double tot = block_sum_256(ss, sh);
   if (threadIdx.x == 0) atomicAdd(&p.sumsq[v * 8 + (blockIdx.x & 7)], tot);
@@ -288,8 +302,8 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
 }
 void launch_vode_grad(const VodeGradP& p, hipStream_t st) {
   long long nl4 = p.nl / 4;
-  long long bx = (nl4 + 255) / 256;
-  if (bx > 512) bx = 512;
+  long long bx = (nl4 + 511) / 512;     // two float4 per thread and iteration
+  if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(vode_grad_kernel, dim3((unsigned)bx, p.nlay), dim3(256), 0, st, p);
 }
