@@ -6,6 +6,7 @@ from .config import (DEFAULT_CONFIG, MODEL_CONFIGS, ModelConfig, TransformerConf
                      transformer_config_from)
 from .model import (STATUS, STATUS_FORWARD, LayerParam, TransformerDecoder, VodeParam, energy, forward,
                     layer_energies, step, step_energies, train_on_batch)
+from .inference import calculate_psnr, extract_features_from_batch, make_mask, unmask_on_batch_enhanced
 from .optim import (Optim, adamw, chain, clip_by_global_norm, create_learning_rate_schedule,
                     make_optimizers, sgd)
 from .serialisation import load_params, save_params
@@ -15,5 +16,6 @@ __all__ = [
     "transformer_config_from", "STATUS", "STATUS_FORWARD", "LayerParam", "TransformerDecoder",
     "VodeParam", "energy", "forward", "layer_energies", "step", "step_energies", "train_on_batch",
     "Optim", "adamw", "chain", "clip_by_global_norm", "create_learning_rate_schedule",
-    "make_optimizers", "sgd", "load_params", "save_params",
+    "make_optimizers", "sgd", "load_params", "save_params", "calculate_psnr", "extract_features_from_batch",
+    "make_mask", "unmask_on_batch_enhanced",
 ]

@@ -60,6 +60,7 @@ SIGNATURES = {
     "cora_get_energies": (C.c_int, [_P, C.c_int, _P, _P]),
     "cora_forward": (C.c_int, [_P, _P, _SZ]),
     "cora_energy": (C.c_int, [_P, _P, _DP, _P, _P, _SZ]),
+    "cora_unmask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
     "cora_profile_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "cora_sync": (C.c_int, [_P]),
 }

@@ -115,8 +115,16 @@ struct UpdateP {
   const double* sumsq;  // [nlayers] sums of squares of the (scaled) grads of this step
   float clip, mu; const float* eta; int t;
   int use_grad_norm; float grad_norm_target;
+  // un-frozen sensory vode (inpainting loop, src/decoder_transformer.py:904-906): one more leaf in
+  // the global norm.  Its gradient is g_s = sens_s * e_img, so ||g_s||^2 = 2 sens_s^2 * (1/2 sum e_img^2),
+  // and the sensory energy is already reduced into sens_e[0..sens_n).  Null: sensory vode frozen.
+  const double* sens_e; int sens_n; float sens_s;
 };
 void launch_update(const UpdateP& p, hipStream_t st);
+// sensory state (patch layout, n floats): m_s = c g_s + mu m_s ; h_s -= eta m_s, same multipliers as launch_update
+void launch_sens_update(const UpdateP& p, float* hs, float* ms, const float* e_img, long long n, hipStream_t st);
+// soft clamp of the known pixels, :982-994: h_s = mask == 0 ? alpha x + (1 - alpha) h_s : h_s
+void launch_sens_clamp(float* hs, const float* xt, const float* mask, float alpha, long long n, hipStream_t st);
 // Fused path, pass 1 of the vode step: g_v = s_v (e_v + l1 sign(h_v) + 2 l2 h_v - bp_v) for vodes 1..L+1,
 // its sum of squares (8 slots per vode) and the vode energies 1/2 e^2 + l1 |h| + l2 h^2 (8 slots per vode).
 // bp and g may be the same array.  launch_update then applies clip + momentum SGD.

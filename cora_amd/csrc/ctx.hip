@@ -64,6 +64,11 @@ struct cora_ctx {
   unsigned long long* dbg = nullptr;
   float* gscale = nullptr;   // [L] layer scale of the vode each block reads
   float* eta_dev = nullptr;  // [Tmax]
+  // inpainting loop (cora_unmask): ground truth and mask in patch layout, momentum of the un-frozen
+  // sensory vode (allocated on first use); sens_live marks the sensory vode as un-frozen
+  float *xt = nullptr, *mk = nullptr, *msens = nullptr;
+  bool sens_live = false;
+  float sens_scale = 1.f;
   double* energies = nullptr;  // [(Tmax+2), L+3]
   double* sumsq = nullptr;     // [(Tmax+2), L+2, 8 slots]
   double* esum = nullptr;      // [(Tmax+2), L+3, 8 slots]  energy slots of the fused inference step
@@ -389,9 +394,18 @@ int infer_step(cora_ctx* c, int t) {
   u.h = c->Hs; u.m = c->Ms; u.g = c->Gs; u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
   u.sumsq = ss; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
   u.use_grad_norm = c->cfg.use_grad_norm; u.grad_norm_target = c->cfg.grad_norm_target;
+  if (c->sens_live) {   // un-frozen sensory vode: one more leaf in the clip norm, then its own update
+    if (c->fused) { u.sens_e = c->esum + ((long long)t * (L + 3) + (L + 2)) * 8; u.sens_n = 8; }
+    else { u.sens_e = c->energies + (long long)t * (L + 3) + (L + 2); u.sens_n = 1; }
+    u.sens_s = c->sens_scale;
+  }
   {
     KScope s(c, K_UPDATE, 0, 20.0 * c->nV);
     launch_update(u, c->st);
+  }
+  if (c->sens_live) {
+    KScope s(c, K_OTHER, 0, 20.0 * c->n0);
+    launch_sens_update(u, c->xp, c->msens, err_ptr(c, L + 2), c->n0, c->st);
   }
   return 0;
 }
@@ -555,6 +569,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     if (cfg->use_scaling) s = (float)pow((double)cfg->scale_base, (double)(c->L + 1 - l));
     c->scale_l[l] = s;
   }
+  c->sens_scale = cfg->use_scaling ? (float)pow((double)cfg->scale_base, -1.0) : 1.f;   // vode index L+2
   for (int g = 0; g < 64; ++g) gs[g] = (g <= c->L) ? c->scale_l[g + 1] : 1.f;
   if (hipMemcpyAsync(c->gscale, gs, sizeof gs, hipMemcpyHostToDevice, c->st) != hipSuccess ||
       hipStreamSynchronize(c->st) != hipSuccess) { c->err = "initial upload failed"; return fail(-2); }
@@ -977,6 +992,72 @@ int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, 
   if (xhat) {
     out_proj(c, vode_ptr(c, c->Hs, L + 1), c->z, OUT_STORE, nullptr, nullptr);
     return download_image(c, c->z, xhat, n);
+  }
+  return 0;
+}
+
+// `unmask_on_batch_enhanced` (src/decoder_transformer.py:833-1046): see include/cora_hip.h
+int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const float* mask, int use_corruption,
+                int status_init, int T, const float* eta_h, float alpha, float* recons, float* xhat,
+                float* sensory, double* grad_norms) {
+  if (!c) return -1;
+  if (T < 0 || T > c->Tmax) FAIL(-1, "T out of range (0..max_T)");
+  if (!x_true || !x_init) FAIL(-1, "x_true / x_init is NULL");
+  if (T > 0 && !eta_h) FAIL(-1, "eta_h is NULL");
+  if (use_corruption && !mask) FAIL(-1, "use_corruption needs a mask");
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L;
+  int rc = 0;
+  if (use_corruption && !c->msens) {
+    if ((rc = dalloc(c, &c->xt, c->n0)) || (rc = dalloc(c, &c->mk, c->n0)) || (rc = dalloc(c, &c->msens, c->n0))) return rc;
+  }
+  if (use_corruption) {   // ground truth and mask go to patch layout once (patchify is a permutation)
+    HCHECK(hipMemcpyAsync(c->ximg, x_true, sizeof(float) * (size_t)c->nImg, hipMemcpyHostToDevice, c->st));
+    launch_patchify(c->ximg, c->xt, c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 0, c->st);
+    HCHECK(hipMemcpyAsync(c->ximg, mask, sizeof(float) * (size_t)c->nImg, hipMemcpyHostToDevice, c->st));
+    launch_patchify(c->ximg, c->mk, c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 0, c->st);
+    launch_zero(c->msens, sizeof(float) * (size_t)c->n0, c->st);
+  }
+  if ((rc = upload_x(c, x_init, 0))) return rc;             // forward(x_init): the sensory vode takes x_init, :900-901
+  if (status_init && (rc = chain_forward(c, true))) return rc;   // STATUS.INIT: h_l := u_l chained from h_0
+  if (T > 0) HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  launch_zero(c->energies, ((sizeof(double) * (size_t)(T + 1) * (L + 3)) + 15) / 16 * 16, c->st);
+  launch_zero(c->sumsq, sizeof(double) * (size_t)(T + 1) * (L + 2) * 8, c->st);
+  launch_zero(c->esum, sizeof(double) * (size_t)(T + 1) * (L + 3) * 8, c->st);
+  launch_zero(c->Ms, sizeof(float) * (size_t)c->nV, c->st);   // optim_h.init, :841
+  c->sens_live = use_corruption != 0;                        // :904-911
+  c->last_T = T;
+  for (int t = 0; t < T && !rc; ++t) {
+    if (recons) {                                            // reconstruction BEFORE the step, :916-919
+      if ((rc = chain_forward(c, false))) break;
+      if ((rc = download_image(c, c->z, recons + (size_t)t * c->nImg, (size_t)c->nImg))) break;
+    }
+    if ((rc = infer_step(c, t))) break;                      // :922-965
+    if (use_corruption) launch_sens_clamp(c->xp, c->xt, c->mk, alpha, c->n0, c->st);   // :982-994
+  }
+  c->sens_live = false;                                      // re-frozen, :1037
+  if (rc) return rc;
+  if ((rc = chain_forward(c, false))) return rc;             // :1002-1004
+  if (xhat && (rc = download_image(c, c->z, xhat, (size_t)c->nImg))) return rc;
+  if (sensory && (rc = download_image(c, c->xp, sensory, (size_t)c->nImg))) return rc;
+  HCHECK(hipStreamSynchronize(c->st));
+  if (grad_norms) {   // [T, L+3]: L2 norm of the (scaled) gradient of every vode, the quantity logged at :936-958
+    std::vector<double> s8((size_t)(L + 2) * 8), en((size_t)L + 3);
+    for (int t = 0; t < T; ++t) {
+      HCHECK(hipMemcpy(s8.data(), c->sumsq + (long long)t * (L + 2) * 8, sizeof(double) * s8.size(), hipMemcpyDeviceToHost));
+      for (int l = 0; l < L + 2; ++l) {
+        double n2 = 0.0;
+        for (int k = 0; k < 8; ++k) n2 += s8[(size_t)l * 8 + k];
+        grad_norms[(size_t)t * (L + 3) + l] = sqrt(n2);
+      }
+      double gs = 0.0;
+      if (use_corruption) {
+        if (energy_row(c, t, en.data())) FAIL(-2, "energy read-back failed");
+        gs = sqrt(2.0 * en[L + 2]) * (double)c->sens_scale;
+      }
+      grad_norms[(size_t)t * (L + 3) + L + 2] = gs;
+    }
   }
   return 0;
 }

@@ -200,30 +200,47 @@ void launch_patchify(const float* img, float* xp, int B, int F, int C, int Himg,
 }
 
 // ---- vode update ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
-  // per-layer multiplier: optional per-leaf normalisation, then the global-norm clip over all leaves
-  __shared__ float mult_sh[64];
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int l = 0; l < p.nlayers; ++l) {
-      double n2 = 0.0;
-      for (int k = 0; k < 8; ++k) n2 += p.sumsq[l * 8 + k];
-      float m = 1.f;
-      if (p.use_grad_norm) {
-        double nrm = sqrt(n2);
-        m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
-        n2 = n2 * (double)m * (double)m;
-      }
-      mult_sh[l] = m;
-      tot += n2;
+// per-leaf multipliers: optional per-leaf normalisation, then the global-norm clip over all leaves
+// (mult[nlayers] is the un-frozen sensory leaf's, layer scale included).  One thread.
+__device__ void vode_multipliers(const UpdateP& p, float* mult) {
+  double tot = 0.0;
+  for (int l = 0; l < p.nlayers; ++l) {
+    double n2 = 0.0;
+    for (int k = 0; k < 8; ++k) n2 += p.sumsq[l * 8 + k];
+    float m = 1.f;
+    if (p.use_grad_norm) {
+      double nrm = sqrt(n2);
+      m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
+      n2 = n2 * (double)m * (double)m;
     }
-    float cm = 1.f;
-    if (p.clip > 0.f) {
-      double gn = sqrt(tot);
-      if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
-    }
-    for (int l = 0; l < p.nlayers; ++l) mult_sh[l] *= cm;
+    mult[l] = m;
+    tot += n2;
   }
+  mult[p.nlayers] = 0.f;
+  if (p.sens_e) {
+    double es = 0.0;
+    for (int k = 0; k < p.sens_n; ++k) es += p.sens_e[k];
+    double n2 = 2.0 * (double)p.sens_s * (double)p.sens_s * es;
+    float m = 1.f;
+    if (p.use_grad_norm) {
+      double nrm = sqrt(n2);
+      m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
+      n2 = n2 * (double)m * (double)m;
+    }
+    mult[p.nlayers] = m * p.sens_s;
+    tot += n2;
+  }
+  float cm = 1.f;
+  if (p.clip > 0.f) {
+    double gn = sqrt(tot);
+    if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
+  }
+  for (int l = 0; l <= p.nlayers; ++l) mult[l] *= cm;
+}
+
+__global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
+  __shared__ float mult_sh[66];
+  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
   __syncthreads();
   const float eta = p.eta[p.t];
   const long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
@@ -241,12 +258,51 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
     *reinterpret_cast<float4*>(p.h + e) = h;
   }
 }
+__global__ __launch_bounds__(256) void sens_update_kernel(UpdateP p, float* __restrict__ hs, float* __restrict__ ms,
+                                                          const float* __restrict__ e_img, long long n4) {
+  __shared__ float mult_sh[66];
+  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
+  __syncthreads();
+  const float mul = mult_sh[p.nlayers], eta = p.eta[p.t];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 g = reinterpret_cast<const float4*>(e_img)[i];
+    float4 m = reinterpret_cast<float4*>(ms)[i];
+    float4 h = reinterpret_cast<float4*>(hs)[i];
+    m.x = g.x * mul + p.mu * m.x; m.y = g.y * mul + p.mu * m.y;
+    m.z = g.z * mul + p.mu * m.z; m.w = g.w * mul + p.mu * m.w;
+    h.x -= eta * m.x; h.y -= eta * m.y; h.z -= eta * m.z; h.w -= eta * m.w;
+    reinterpret_cast<float4*>(ms)[i] = m;
+    reinterpret_cast<float4*>(hs)[i] = h;
+  }
+}
+__global__ __launch_bounds__(256) void sens_clamp_kernel(float* __restrict__ hs, const float* __restrict__ xt,
+                                                         const float* __restrict__ mask, float alpha, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float cur = hs[i];
+    float target = (mask[i] == 0.f) ? xt[i] : cur;
+    hs[i] = alpha * target + (1.0f - alpha) * cur;
+  }
+}
 void launch_update(const UpdateP& p, hipStream_t st) {
   long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
+void launch_sens_update(const UpdateP& p, float* hs, float* ms, const float* e_img, long long n, hipStream_t st) {
+  long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sens_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, hs, ms, e_img, n4);
+}
+void launch_sens_clamp(float* hs, const float* xt, const float* mask, float alpha, long long n, hipStream_t st) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sens_clamp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hs, xt, mask, alpha, n);
 }
 
 // ---- fused path, pass 1 of the vode step (see VodeGradP) ---------------------------------------------

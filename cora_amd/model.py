@@ -344,6 +344,18 @@ class TransformerDecoder:
             self._optim_sig = sig
         return rh, rw
 
+    def _apply_recipes_h(self, optim_h: Optim):
+        """Vode-optimizer half only (inference-only loops); the weight half keeps its last values."""
+        rh = optim_h._recipe()
+        if not isinstance(rh.base, sgd):
+            raise NotImplementedError("vode optimizer must be sgd(lr, momentum) (AdamW-for-h: SURVEY 8(f) rank 4)")
+        prev = self._optim_sig or (0.0, 0.0, 0.0, 0.9, 0.999, 1e-8, 0.0)
+        sig = (float(rh.clip or 0.0), float(rh.base.momentum or 0.0)) + tuple(prev[2:])
+        if sig != self._optim_sig:
+            _lib.check(_lib.load().cora_set_optim(self._ctx, *[C.c_float(v) for v in sig]), self._ctx)
+            self._optim_sig = sig
+        return rh
+
     # -- adam state (optimizer state is not part of the reference's checkpoints, but is exposed) ----
     def get_adam_state(self):
         mu = np.empty(self._nW, dtype=np.float32)

@@ -134,6 +134,21 @@ int cora_get_energies(cora_ctx* ctx, int T, double* total, double* per_layer);
 
 /* `forward(None, model=...)` under status "forward" (:488-489): xhat [B,C,H,W] to the host. */
 int cora_forward(cora_ctx* ctx, float* xhat_host, size_t n_floats);
+/* `unmask_on_batch_enhanced` (/root/reference/src/decoder_transformer.py:833-1046): the inference-only /
+ * inpainting loop.  x_true, x_init, mask: host [B,C,H,W] (mask already broadcast over channels,
+ * 1 = masked; ignored unless use_corruption).  The sensory vode starts from x_init (:896-901); with
+ * use_corruption it is un-frozen for the T steps (:904-906): gradient h_s - u with layer scale
+ * base^-1 (:324-326), part of the global-norm clip and the momentum step (:965), then the known
+ * pixels are blended towards x_true with weight alpha (:982-994).  status_init != 0 re-chains
+ * h_l := u_l from the current h_0 first (:899-901; h_0 itself is whatever cora_set_vode left).
+ * Outputs (host, each may be NULL): recons [T,B,C,H,W] = status-"forward" reconstruction before
+ * every step (:916-919); xhat = the final one (:1002-1004); sensory = final sensory state;
+ * grad_norms [T, L+3] = L2 norm of every vode's scaled gradient per step (:936-958).
+ * eta_h[T] as in cora_infer.  The loss (:1006-1034) is plain host arithmetic on xhat. */
+int cora_unmask(cora_ctx* ctx, const float* x_true, const float* x_init, const float* mask,
+                int use_corruption, int status_init, int T, const float* eta_h, float alpha,
+                float* recons, float* xhat, float* sensory, double* grad_norms);
+
 /* `energy(model=...)` (:302-305) with the sensory vode set to x (host, may be NULL to keep the
  * last one): batch-summed E, per-vode E [L+3] (may be NULL) and the status-None prediction. */
 int cora_energy(cora_ctx* ctx, const float* x_host, double* E, double* per_layer,

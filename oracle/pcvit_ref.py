@@ -385,3 +385,66 @@ def energy_and_prediction(h, weights, pos, x, dims: Dims, hp: Hyper, dtype=torch
         us = predictions(hs, W, pos_t, dims)
         Es = layer_energies(hs, us, y, hp.l1, hp.l2)
     return float(sum(Es)), np.array([float(e) for e in Es]), us[-1].numpy()
+
+
+def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Optional[np.ndarray],
+                    weights, h: List[np.ndarray], pos, dims: Dims, hp: Hyper, eta_h: Sequence[float],
+                    alpha: float = 1.0, use_corruption: bool = True, status_init: bool = False,
+                    dtype=torch.float64):
+    """`unmask_on_batch_enhanced` (src/decoder_transformer.py:833-1046), the inference-only /
+    inpainting loop.  x_init is what the sensory vode starts from (the corrupted image, :896,900-901),
+    mask is [B,1,H,W] with 1 = masked (:882-894).  With use_corruption the sensory vode is un-frozen
+    (:904-906): it gets the gradient dE/dh_s = h_s - u_{L+2}, the layer scale base^{(L+1)-(L+2)}
+    (:324-326 with vode index L+2), takes part in the global-norm clip and the momentum step (:965),
+    and after each step the known pixels are blended back towards the ground truth (:982-994).
+    status_init: the INIT pass of :899-901 re-chains h_l := u_l from h_0 (h_0 itself is kept: the
+    reference re-draws it from its own RNG, which is not reproduced).  Returns the per-step
+    status-"forward" reconstructions (:916-919), the final one (:1002-1004), the loss (:1006-1032)
+    and the final states."""
+    W = {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+    pos_t = torch.as_tensor(np.asarray(pos), dtype=dtype)
+    hs = [torch.as_tensor(np.asarray(t), dtype=dtype) for t in h]
+    xt = torch.as_tensor(np.asarray(x_true), dtype=dtype)
+    hsens = torch.as_tensor(np.asarray(x_init), dtype=dtype).clone()
+    if status_init:
+        with torch.no_grad():
+            us = predictions([hs[0]], W, pos_t, dims, chain=True)
+        hs = [hs[0]] + list(us[:-1])
+    mk = None
+    if use_corruption and mask is not None:
+        mk = torch.as_tensor(np.asarray(mask), dtype=dtype).expand_as(xt)
+    state = hs + ([hsens] if use_corruption else [])
+    mom = [torch.zeros_like(t) for t in state]
+    recons, energies, norms = [], [], []
+    for t in range(T):
+        with torch.no_grad():
+            recons.append(predictions(hs, W, pos_t, dims, chain=True)[-1].numpy())
+        hv = [s.detach().clone().requires_grad_(True) for s in state]
+        y = hv[-1] if use_corruption else hsens
+        us = predictions(hv[:dims.L + 2], W, pos_t, dims)
+        E = sum(layer_energies(hv[:dims.L + 2], us, y, hp.l1, hp.l2))
+        grads = torch.autograd.grad(E, hv, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(s) for g, s in zip(grads, hv)]
+        energies.append(float(E.detach()))
+        g_scaled = scale_h_grads(grads, dims, hp)        # vode index L+2 -> base^-1
+        norms.append([float(torch.sqrt((g * g).sum())) for g in g_scaled])
+        g_clip = _clip(g_scaled, hp.clip_h)
+        mom = [g + hp.momentum * m for g, m in zip(g_clip, mom)]
+        state = [s - eta_h[t] * m for s, m in zip(state, mom)]
+        hs = state[:dims.L + 2]
+        if use_corruption:
+            cur = state[-1]
+            target = torch.where(mk == 0, xt, cur)
+            state[-1] = alpha * target + (1.0 - alpha) * cur
+            hsens = state[-1]
+    with torch.no_grad():
+        xhat = predictions(hs, W, pos_t, dims, chain=True)[-1]
+    if use_corruption:
+        nm = mk.sum()
+        nu = float(xhat.numel()) - nm
+        d2 = (xhat.clamp(0.0, 1.0) - xt) ** 2
+        loss = ((d2 * mk).sum() / torch.clamp(nm, min=1e-8) + (d2 * (1 - mk)).sum() / torch.clamp(nu, min=1e-8)) / 2
+    else:
+        loss = ((xhat.clamp(0.0, 1.0).reshape(-1) - xt.reshape(-1)) ** 2).mean()
+    return {"recons": recons, "xhat": xhat.numpy(), "loss": float(loss), "energies": np.array(energies),
+            "grad_norms": np.array(norms), "h": [t.numpy() for t in hs], "sensory": hsens.numpy()}

@@ -1,0 +1,122 @@
+"""GPU parity of the inference-only loops: `unmask_on_batch_enhanced`
+(/root/reference/src/decoder_transformer.py:833-1046) and the linear-probe feature extractor
+(/root/reference/examples/linear_probe.py:195-288), HIP path through the C-ABI against the fp64
+oracle on identical seeded inputs.  Bar: rel <= 1e-4 (or 3x the fp32 floor of the oracle itself,
+see tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pcvit_ref as R
+from tests.util import build_model, make_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+SHAPES = {
+    # name: (image_shape, patch, D, H, L, B, T)
+    "fused_shape": ((3, 32, 32), 4, 64, 1, 3, 3, 4),     # N=64, D=64, H=1: the fused kernel path
+    "general_h2": ((3, 16, 16), 4, 32, 2, 2, 4, 4),      # general (per-op) path
+}
+
+
+def _cmp(errs, floor, key, got, want, f32):
+    want = np.asarray(want, dtype=np.float64)
+    sc = np.abs(want).max() + 1e-30
+    errs[key] = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / sc)
+    floor[key] = float(np.abs(np.asarray(f32, dtype=np.float64) - want).max() / sc)
+
+
+def _check(name, errs, floor):
+    bad = {k: (v, floor[k]) for k, v in errs.items() if not v <= max(TOL, 3.0 * floor[k])}
+    assert not bad, f"{name}: parity failures (err, fp32 floor): {bad}"
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("lower_half,alpha,clip_h", [(True, 1.0, 2000.0), (False, 0.6, 3.0)])
+def test_unmask_with_corruption(name, lower_half, alpha, clip_h):
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = SHAPES[name]
+    case = make_case(shape, p, D, H, L, B, seed=21, clip_h=clip_h)
+    model, optim_w, optim_h = build_model(case)
+    model.config.use_lower_half_mask = lower_half
+    model.config.inference_clamp_alpha = alpha
+    x = case["x"]
+    mask, x_init = ca.make_mask(model, x, 0.5, np.random.default_rng(3))
+    args = (T, x, x_init, mask, case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T)
+    ref = R.unmask_on_batch(*args, alpha=alpha, use_corruption=True)
+    r32 = R.unmask_on_batch(*args, alpha=alpha, use_corruption=True, dtype=torch.float32)
+    loss, recons, mask_out, log = ca.unmask_on_batch_enhanced(
+        True, 0.5, [2, T], x, model=model, optim_h=optim_h, log_inference_grads=True, rng=np.random.default_rng(3))
+    assert np.array_equal(mask_out, mask) and len(recons) == T
+    errs, floor = {}, {}
+    for t in range(T):
+        _cmp(errs, floor, f"recon{t}", recons[t], ref["recons"][t], r32["recons"][t])
+        got = [log[t][f"vode_{i}_grad_norm"] for i in range(L + 3)]
+        _cmp(errs, floor, f"gnorm{t}", got, ref["grad_norms"][t], r32["grad_norms"][t])
+    with ca.step(model, ca.STATUS_FORWARD):
+        xhat = ca.forward(None, model=model)
+    _cmp(errs, floor, "xhat", xhat, ref["xhat"], r32["xhat"])
+    _cmp(errs, floor, "sensory", model.vodes[L + 2].h.get(), ref["sensory"], r32["sensory"])
+    _cmp(errs, floor, "loss", loss, ref["loss"], r32["loss"])
+    for l in range(L + 2):
+        _cmp(errs, floor, f"h{l}", model.vodes[l].h.get(), ref["h"][l], r32["h"][l])
+    if alpha == 1.0:   # hard clamp: the known pixels are exactly the ground truth after every step
+        s = model.vodes[L + 2].h.get()
+        mb = np.broadcast_to(mask, s.shape)
+        assert np.array_equal(s[mb == 0], x[mb == 0])
+    model.close()
+    _check(name, errs, floor)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_unmask_without_corruption_and_features(name):
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = SHAPES[name]
+    case = make_case(shape, p, D, H, L, B, seed=22)
+    model, optim_w, optim_h = build_model(case)
+    x = case["x"]
+    args = (T, x, x, None, case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T)
+    ref = R.unmask_on_batch(*args, use_corruption=False)
+    r32 = R.unmask_on_batch(*args, use_corruption=False, dtype=torch.float32)
+    loss, recons, mask_out, log = ca.unmask_on_batch_enhanced(False, 0.0, [T], x, model=model, optim_h=optim_h)
+    assert mask_out.shape == x.shape and not mask_out.any() and log == {}
+    errs, floor = {}, {}
+    for t in range(T):
+        _cmp(errs, floor, f"recon{t}", recons[t], ref["recons"][t], r32["recons"][t])
+    _cmp(errs, floor, "loss", loss, ref["loss"], r32["loss"])
+    for l in range(L + 2):
+        _cmp(errs, floor, f"h{l}", model.vodes[l].h.get(), ref["h"][l], r32["h"][l])
+    assert np.array_equal(model.vodes[L + 2].h.get(), x)        # frozen sensory vode
+    # linear-probe features: same loop from the same start, then GAP over tokens of vodes 1 and L+1
+    for l, t in enumerate(case["h"]):
+        model.vodes[l].h.set(t)
+    f = ca.extract_features_from_batch(x, model, optim_h, T, [1, -2], True)
+    want = np.concatenate([ref["h"][1], ref["h"][L + 1]], axis=-1).mean(axis=1)
+    w32 = np.concatenate([r32["h"][1], r32["h"][L + 1]], axis=-1).mean(axis=1)
+    assert f.shape == (B, 2 * D)
+    _cmp(errs, floor, "features", f, want, w32)
+    model.close()
+    _check(name, errs, floor)
+
+
+def test_unmask_status_init_flag():
+    """status_init of the C entry point: h_l := u_l re-chained from the current h_0 before the loop."""
+    import ctypes as C
+    import cora_amd as ca
+    from cora_amd import _lib
+    from cora_amd.model import _fptr
+    shape, p, D, H, L, B, T = SHAPES["fused_shape"]
+    case = make_case(shape, p, D, H, L, B, seed=23)
+    model, optim_w, optim_h = build_model(case)
+    model._apply_recipes_h(optim_h)
+    x = case["x"]
+    eta = np.full(T, 0.095, dtype=np.float32)
+    ref = R.unmask_on_batch(T, x, x, None, case["W"], case["h"], case["pos"], case["dims"], case["hp"], list(eta),
+                            use_corruption=False, status_init=True)
+    xhat = np.empty_like(x)
+    _lib.check(_lib.load().cora_unmask(model._ctx, _fptr(x), _fptr(x), None, 0, 1, T, _fptr(eta), C.c_float(1.0),
+                                       None, _fptr(xhat), None, None), model._ctx)
+    sc = np.abs(ref["xhat"]).max()
+    assert np.abs(xhat - ref["xhat"]).max() / sc <= 2e-4
+    model.close()

@@ -139,3 +139,25 @@ def test_unsupported_modes_raise():
         ca.TransformerDecoder(ca.create_config(update_weights_every_inference_step=True))
     with pytest.raises(NotImplementedError):
         ca.TransformerDecoder(ca.create_config(use_vode_state_layernorm=True))
+
+
+def test_make_mask_and_psnr():
+    """Host halves of unmask_on_batch_enhanced: the two corruptions (:868-896) and calculate_psnr (:815-830)."""
+    import cora_amd as ca
+    cfg = ca.TransformerConfig(image_shape=(3, 8, 8), hidden_size=16, num_heads=1, num_blocks=1, patch_size=4,
+                               update_weights_every_inference_step=False)
+    model = ca.TransformerDecoder(cfg)
+    x = np.random.default_rng(0).uniform(0, 1, (2, 3, 8, 8)).astype(np.float32)
+    model.config.use_lower_half_mask = True
+    mask, xc = ca.make_mask(model, x, 0.3)
+    assert mask.shape == (2, 1, 8, 8) and mask[:, :, 6:].all() and not mask[:, :, :6].any()   # floor(8*0.3) = 2 rows
+    assert (xc[:, :, 6:] == 0.5).all() and np.array_equal(xc[:, :, :6], x[:, :, :6])
+    mask0, xc0 = ca.make_mask(model, x, 0.0)
+    assert not mask0.any() and np.array_equal(xc0, x)
+    model.config.use_lower_half_mask = False
+    mask, xc = ca.make_mask(model, x, 0.5, np.random.default_rng(1))
+    mb = np.broadcast_to(mask, x.shape)
+    assert set(np.unique(mask)) <= {0.0, 1.0} and 0.2 < mask.mean() < 0.8
+    assert np.array_equal(xc[mb == 0], x[mb == 0]) and np.abs(xc[mb == 1]).max() < 1.0
+    assert ca.calculate_psnr(x, x) == pytest.approx(80.0)            # epsilon floor: 10 log10(1 / 1e-8)
+    assert ca.calculate_psnr(np.zeros(4), np.full(4, 0.1)) == pytest.approx(20.0)

@@ -135,3 +135,34 @@ def test_oracle_reproduces_golden(name):
 def test_golden_files_all_listed():
     files = {os.path.basename(f)[:-4] for f in glob.glob(os.path.join(HERE, "golden", "*.npz"))}
     assert files == set(GOLDEN)
+
+
+def test_unmask_oracle_consistency():
+    """Inference-only loop restatement (src/decoder_transformer.py:833-1046): without corruption it
+    is the T-step loop of train_on_batch with the sensory vode frozen; with a hard clamp (alpha = 1)
+    the known pixels equal the ground truth after every step and the un-frozen sensory vode adds
+    one gradient leaf scaled by base^-1."""
+    from tests.util import make_case
+    case = make_case((3, 16, 16), 4, 32, 2, 2, 2, seed=1)
+    x = case["x"]
+    T = 3
+    common = (case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T)
+    r0 = R.unmask_on_batch(T, x, x, None, *common, use_corruption=False)
+    tr = R.train_on_batch(T, x, case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T, 1e-3)
+    for a, b in zip(r0["h"], tr["h"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(r0["sensory"], x.astype(np.float64))
+    m = np.zeros((2, 1, 16, 16), np.float32)
+    m[:, :, 8:] = 1
+    xi = np.where(m == 1, 0.5, x).astype(np.float32)
+    r1 = R.unmask_on_batch(T, x, xi, m, *common, alpha=1.0)
+    mb = np.broadcast_to(m, x.shape)
+    assert np.array_equal(r1["sensory"][mb == 0], x.astype(np.float64)[mb == 0])
+    assert r1["grad_norms"].shape == (T, case["dims"].L + 3) and (r1["grad_norms"][:, -1] > 0).all()
+    assert len(r1["recons"]) == T and r1["loss"] > 0
+    # first-step sensory gradient norm = ||x_init - u|| / base  (layer scale base^{(L+1)-(L+2)})
+    us = R.predictions([torch.as_tensor(t, dtype=torch.float64) for t in case["h"]],
+                       {k: torch.as_tensor(v, dtype=torch.float64) for k, v in case["W"].items()},
+                       torch.as_tensor(case["pos"], dtype=torch.float64), case["dims"])
+    want = float(torch.sqrt(((torch.as_tensor(xi, dtype=torch.float64) - us[-1]) ** 2).sum())) / case["hp"].scale_base
+    assert abs(r1["grad_norms"][0, -1] - want) <= 1e-9 * want
