@@ -120,3 +120,27 @@ def test_unmask_status_init_flag():
     sc = np.abs(ref["xhat"]).max()
     assert np.abs(xhat - ref["xhat"]).max() / sc <= 2e-4
     model.close()
+
+
+def test_train_epoch_and_pretext_metrics():
+    """`train` (:601-690) is the mean of per-batch train_on_batch scalars; `eval_pretext_metrics`
+    (:502-598) recomputes its metrics from the last per-step reconstruction."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = SHAPES["fused_shape"]
+    case = make_case(shape, p, D, H, L, B, seed=31)
+    rng = np.random.default_rng(4)
+    batches = [(rng.uniform(0, 1, case["x"].shape).astype(np.float32), None) for _ in range(2)]
+    model, optim_w, optim_h = build_model(case)
+    avg_w, avg_mse, gh, gw = ca.train(batches, T, model=model, optim_w=optim_w, optim_h=optim_h, epoch=0)
+    model2, ow2, oh2 = build_model(case)
+    outs = [ca.train_on_batch(T, xb, model=model2, optim_w=ow2, optim_h=oh2) for xb, _ in batches]
+    assert avg_w == pytest.approx(np.mean([o[1] for o in outs]), rel=1e-6)
+    assert avg_mse == pytest.approx(np.mean([o[4] for o in outs]), rel=1e-6)
+    # two contexts: float atomics in the reductions make runs agree to rounding, not bit for bit
+    assert np.abs(gh[1] - outs[-1][2][1]).max() <= 1e-4 * np.abs(gh[1]).max()
+    model.config.use_lower_half_mask = True
+    m = ca.eval_pretext_metrics(batches, [T], True, 0.5, model=model, optim_h=optim_h)
+    assert set(m) == {"full_mse", "masked_mse", "full_l1", "masked_l1", "full_psnr", "masked_psnr"}
+    assert m["full_mse"] > 0 and m["masked_mse"] > 0 and m["full_psnr"] == pytest.approx(
+        np.mean([10 * np.log10(1.0 / max(v, 1e-8)) for v in [m["full_mse"]]]), abs=1.0)
+    model.close(); model2.close()
