@@ -39,10 +39,10 @@ CASES = {
 }
 
 
-def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0):
+def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, **kw):
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
-    case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000, l1=l1, l2=l2, clip_h=clip_h, clip_w=clip_w)
+    case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000, l1=l1, l2=l2, clip_h=clip_h, clip_w=clip_w, **kw)
     model, optim_w, optim_h = build_model(case)
     eta = [0.095] * T
     args = (T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], eta, 1e-3)
@@ -96,6 +96,13 @@ def test_step_parity(name):
 def test_regularisers_and_clipping():
     # l1/l2 vode regularisers on, and clip thresholds low enough that both clips trigger
     run_case("tiny_2block_h2", l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5)
+
+
+@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4"])
+def test_vode_grad_norm_option(name):
+    # normalize_vode_h_gradients (src/decoder_transformer.py:353-389): per-leaf g / (||g|| + 1e-8) * target,
+    # on the general path and on the fused path; the clip then sees the normalised leaves
+    run_case(name, use_grad_norm=True, grad_norm_target=1.5, clip_h=2.0)
 
 
 def test_two_batches_persistent_state_and_adam():

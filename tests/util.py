@@ -6,7 +6,8 @@ from oracle import pcvit_ref as R
 
 
 def make_case(image_shape, patch, D, H, L, B, seed=0, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0,
-              momentum=0.4, scale_base=1.25, use_scaling=True, theta=10000, h_noise=0.05):
+              momentum=0.4, scale_base=1.25, use_scaling=True, theta=10000, h_noise=0.05,
+              use_grad_norm=False, grad_norm_target=1.0):
     from cora_amd.params import init_params
     from cora_amd.posenc import create_positional_encoding
     dims = R.Dims(tuple(image_shape), patch, D, H, L)
@@ -21,7 +22,7 @@ def make_case(image_shape, patch, D, H, L, B, seed=0, l1=0.0, l2=0.0, clip_h=200
     h = R.init_vodes(h0, W, pos, dims)
     h = [(t + h_noise * rng.standard_normal(t.shape)).astype(np.float32) for t in h]
     hp = R.Hyper(l1=l1, l2=l2, use_scaling=use_scaling, scale_base=scale_base, clip_h=clip_h,
-                 clip_w=clip_w, momentum=momentum)
+                 clip_w=clip_w, momentum=momentum, use_grad_norm=use_grad_norm, grad_norm_target=grad_norm_target)
     return dict(dims=dims, W=W, pos=pos, x=x, h=h, hp=hp, h0=h0)
 
 
@@ -33,7 +34,8 @@ def build_model(case, max_T=64):
         patch_size=d.patch_size, use_noise=True, use_inference_lr_scaling=hp.use_scaling,
         inference_lr_scale_base=hp.scale_base, update_weights_every_inference_step=False,
         use_status_init_in_training=False, use_status_init_in_unmasking=False,
-        intermediate_l1_coeff=hp.l1, intermediate_l2_coeff=hp.l2)
+        intermediate_l1_coeff=hp.l1, intermediate_l2_coeff=hp.l2,
+        use_vode_grad_norm=hp.use_grad_norm, vode_grad_norm_target=hp.grad_norm_target)
     model = ca.TransformerDecoder(cfg, max_T=max_T)
     model.positional_embedding = case["pos"]
     model.set_weights(case["W"])
