@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's batch_size)")
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = parity path (the headline number); bf16 = opt-in bf16-MFMA mode (per-op path)")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +107,7 @@ def main():
     T = args.T or mc.inference_steps
     lib = _lib.load()
 
-    model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64))
+    model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=args.dtype)
     rng = np.random.default_rng(1234 + rank)
     x_host = rng.uniform(0, 1, (B,) + tuple(tc.image_shape)).astype(np.float32)
     h0 = (0.01 * rng.standard_normal((B, model.N, model.P))).astype(np.float32)
@@ -213,7 +215,7 @@ def main():
             "metric": "PC inference images x T-steps/sec (node)", "value": value, "unit": "images*T-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16 operands / f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.config} PC-ViT train_on_batch: N={model.N} tokens, P={model.P}, "
                                    f"D={model.D}, H={model.H}, L={model.L}, B={B}/GPU, T={T} inference steps + "
                                    "weight update + recon", "global_batch": world * B, "T": T,

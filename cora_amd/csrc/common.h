@@ -71,6 +71,8 @@ struct GemmP {
   int groups, splitk;
   int a_gelu;            // apply tanh-GELU to A while staging (MLP2 reads the pre-activation)
   int b_gelu;            // same for the B operand (weight-gradient of linear2)
+  int bf16;              // opt-in: 1 = operands rounded to bf16 in registers, bf16 MFMA, fp32 accumulate;
+                         // 2 = two-term bf16 split of both operands, three bf16 MFMAs (near-fp32 products)
   float alpha;           // v = alpha * acc (+ bias + pos + res1 + res2)
   const float* bias; long long sBias;
   const float* pos; int posN;

@@ -130,12 +130,15 @@ int dalloc(cora_ctx* c, float** p, long long n) {
 float* vode_ptr(cora_ctx* c, float* base, int l) { return l == 0 ? base : base + c->n0 + (long long)(l - 1) * c->nl; }
 float* err_ptr(cora_ctx* c, int l) { return c->Es + (long long)(l - 1) * c->nl; }  // l = 1..L+1 ; L+2 = e_img
 
-GemmP gemm_base(cora_ctx* c) {
+GemmP gemm_base(cora_ctx* c, int kind = 0 /* 0 forward, 1 backward-data, 2 weight-gradient */) {
   GemmP p;
   memset(&p, 0, sizeof p);
   p.groups = 1; p.splitk = 1; p.alpha = 1.f; p.alpha2 = 1.f; p.mode = OUT_STORE;
   p.l1 = 0.f; p.l2 = 0.f; p.red_stride = 1;
-  (void)c;
+  // bf16 mode: backward-data and weight-gradient GEMMs take plain bf16 operands (their error is
+  // relative to the result); the forward predictions feed e = h - u, which cancels most of u, so
+  // they use the split form (measured: plain bf16 there alone costs 2.5e-2 on the 6-block vodes)
+  p.bf16 = (c->cfg.dtype_mode == 1) ? (kind == 0 ? 2 : 1) : 0;
   return p;
 }
 
@@ -229,7 +232,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   const int D = c->D, M = c->M, H = c->H;
   const int R = (int)c->BN;
   const long long rows = (long long)G * R;
-  GemmP p = gemm_base(c); p.groups = G;
+  GemmP p = gemm_base(c, 1); p.groups = G;
   // da = (r W2) * gelu'(a)
   p.A = r; p.Bw = c->W + c->oW2 + (size_t)b0 * D * M; p.C = c->da;
   p.R = R; p.O = M; p.K = D; p.lda = D; p.ldb = M; p.ldc = M;
@@ -237,7 +240,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   p.mode = OUT_GELUGRAD; p.aux = c->a;
   run_gemm(c, p, false, true);
   // dzn = da W1
-  p = gemm_base(c); p.groups = G;
+  p = gemm_base(c, 1); p.groups = G;
   p.A = c->da; p.Bw = c->W + c->oW1 + (size_t)b0 * M * D; p.C = c->dzn;
   p.R = R; p.O = D; p.K = M; p.lda = M; p.ldb = D; p.ldc = D;
   p.sA = (long long)R * M; p.sB = (long long)M * D; p.sC = (long long)R * D;
@@ -250,7 +253,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
     if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: shape not supported (B*N % 4 != 0 or D too large)");
   }
   // dO = dy Wo
-  p = gemm_base(c); p.groups = G;
+  p = gemm_base(c, 1); p.groups = G;
   p.A = c->dy; p.Bw = c->W + c->oWo + (size_t)b0 * D * D; p.C = c->dO;
   p.R = R; p.O = D; p.K = D; p.lda = D; p.ldb = D; p.ldc = D;
   p.sA = (long long)R * D; p.sB = (long long)D * D; p.sC = (long long)R * D;
@@ -261,7 +264,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
     if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
   }
   // dxn = dqkv Wqkv
-  p = gemm_base(c); p.groups = G;
+  p = gemm_base(c, 1); p.groups = G;
   p.A = c->dqkv; p.Bw = c->W + c->oWqkv + (size_t)b0 * 3 * D * D; p.C = c->dxn;
   p.R = R; p.O = D; p.K = 3 * D; p.lda = 3 * D; p.ldb = D; p.ldc = D;
   p.sA = (long long)R * 3 * D; p.sB = 3LL * D * D; p.sC = (long long)R * D;
@@ -373,13 +376,13 @@ int infer_step(cora_ctx* c, int t) {
   }
   if (!c->fused) {
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
-  GemmP p = gemm_base(c);
+  GemmP p = gemm_base(c, 1);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
   p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[0]; p.red = ss + 0;
   run_gemm(c, p, false, true);
   // vode L+1: g = e_{L+1} + reg - e_img Wout
-  p = gemm_base(c);
+  p = gemm_base(c, 1);
   p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
   p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
@@ -472,7 +475,7 @@ int pick_splitk(long long tiles, int K) {
 // C[g] (+)= -A^T B  with A [rows, R], B [rows, O]  (weight gradient, summed over the rows)
 void wgrad_gemm(cora_ctx* c, int G, const float* A, int R, long long sA, const float* Bm, int O, long long sB,
                 float* C, long long sC, int b_gelu) {
-  GemmP p = gemm_base(c);
+  GemmP p = gemm_base(c, 2);
   p.groups = G;
   p.A = A; p.Bw = Bm; p.C = C;
   p.R = R; p.O = O; p.K = (int)c->BN; p.lda = R; p.ldb = O; p.ldc = O;
@@ -494,7 +497,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   if (!cfg || !out) { g_create_err = "null argument"; return -1; }
   *out = nullptr;
   auto bad = [&](const char* m) { g_create_err = m; return -1; };
-  if (cfg->dtype_mode != 0) return bad("dtype_mode: only 0 (fp32 MFMA) is implemented");
+  if (cfg->dtype_mode != 0 && cfg->dtype_mode != 1) return bad("dtype_mode: 0 (fp32 MFMA, parity path) or 1 (bf16 MFMA operands, fp32 accumulate and state)");
   if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return bad("non-positive dimension");
   if (cfg->D % cfg->H) return bad("hidden_size must be divisible by num_heads");
   if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return bad("D, P and M must be multiples of 4 (16-byte rows)");
@@ -536,7 +539,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
-  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && getenv("CORA_NO_FUSED") == nullptr);
+  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && getenv("CORA_NO_FUSED") == nullptr);
   if (c->fused) {
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;

@@ -1,4 +1,7 @@
-// gemm.hip -- grouped fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused PC epilogues (gfx950).
+// gemm.hip -- grouped GEMM with fused PC epilogues (gfx950): fp32 on v_mfma_f32_32x32x2_f32 (parity
+// path) or, opt-in (GemmP::bf16), operands rounded to bf16 on the way from LDS to the matrix core
+// and v_mfma_f32_32x32x16_bf16 with fp32 accumulation (plain, or the two-term split for the
+// forward predictions); everything in HBM / LDS stays fp32.
 //
 // One kernel template serves every dense contraction of the PC-ViT step
 // (K1 patch projection, K3 QKV, K5 Wo, K6 MLP, K7 output projection, K9/K11/K12
@@ -18,7 +21,26 @@
 #define BM 128
 #define BN 64
 
-template <int BK, bool AKO, bool BKO>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16(const float* lo, const float* hi4) {
+  bf16x8 v;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { v[t] = (__bf16)lo[t]; v[4 + t] = (__bf16)hi4[t]; }
+  return v;
+}
+
+// lo part of the two-term bf16 split x = hi + lo (+ O(2^-17 |x|)): what hi's rounding dropped
+__device__ __forceinline__ bf16x8 pack_bf16_lo(const float* lo, const float* hi4, bf16x8 h) {
+  bf16x8 v;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { v[t] = (__bf16)(lo[t] - (float)h[t]); v[4 + t] = (__bf16)(hi4[t] - (float)h[4 + t]); }
+  return v;
+}
+
+// BF16: 0 = fp32 MFMA; 1 = bf16 operands; 2 = split bf16 (A = Ah + Al, B = Bh + Bl, three bf16 MFMAs
+// Ah Bh + Ah Bl + Al Bh): products good to ~2^-16, for the forward predictions whose error
+// e = h - u cancels most leading bits of u
+template <int BK, bool AKO, bool BKO, int BF16>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int LDA_S = AKO ? (BM + 4) : (BK + 4);
   constexpr int LDB_S = BKO ? (BN + 4) : (BK + 4);
@@ -122,9 +144,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     store_tiles();
     __syncthreads();
     if (k0 + BK < kend) load_tiles(k0 + BK);  // prefetch into registers under the MFMAs
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      float a4[4], b4[2][4];
+    // fragments of one 8-deep k group: lane (r, hi) holds k = 8j + 4hi + t, t < 4, of its row / column
+    auto frag = [&](int j, float* a4, float (*b4)[4]) {
       if (!AKO) {
         float4 v = *reinterpret_cast<const float4*>(&As[(32 * w + r) * LDA_S + 8 * j + 4 * hi]);
         a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
@@ -142,10 +163,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           for (int t = 0; t < 4; ++t) b4[n][t] = Bs[(8 * j + 4 * hi + t) * LDB_S + 32 * n + r];
         }
       }
+    };
+    if (!BF16) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[0][t], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[1][t], acc[1], 0, 0, 0);
+      for (int j = 0; j < BK / 8; ++j) {
+        float a4[4], b4[2][4];
+        frag(j, a4, b4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[0][t], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[1][t], acc[1], 0, 0, 0);
+        }
+      }
+    } else {
+      // two k groups make one 32x32x16 bf16 MFMA: the instruction wants 8 k values per lane, and
+      // WHICH 8 is free as long as the A lane and the B lane of the same half agree -- they do
+#pragma unroll
+      for (int j = 0; j < BK / 8; j += 2) {
+        float a4[2][4], b4[2][2][4];
+        frag(j, a4[0], b4[0]);
+        frag(j + 1, a4[1], b4[1]);
+        bf16x8 av = pack_bf16(a4[0], a4[1]);
+        if (BF16 == 1) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pack_bf16(b4[0][n], b4[1][n]), acc[n], 0, 0, 0);
+        } else {
+          bf16x8 al = pack_bf16_lo(a4[0], a4[1], av);
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            bf16x8 bv = pack_bf16(b4[0][n], b4[1][n]);
+            bf16x8 bl = pack_bf16_lo(b4[0][n], b4[1][n], bv);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bv, acc[n], 0, 0, 0);   // small terms first
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[n], 0, 0, 0);
+          }
+        }
       }
     }
   }
@@ -207,16 +260,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int BK>
+template <int BK, int BF16>
 static void launch_bk(const GemmP& p, bool ako, bool bko, dim3 grid, hipStream_t st) {
-  if (!ako && !bko) hipLaunchKernelGGL((gemm_kernel<BK, false, false>), grid, dim3(256), 0, st, p);
-  else if (!ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, false, true>), grid, dim3(256), 0, st, p);
-  else if (ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, true, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<BK, true, false>), grid, dim3(256), 0, st, p);
+  if (!ako && !bko) hipLaunchKernelGGL((gemm_kernel<BK, false, false, BF16>), grid, dim3(256), 0, st, p);
+  else if (!ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, false, true, BF16>), grid, dim3(256), 0, st, p);
+  else if (ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, true, true, BF16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<BK, true, false, BF16>), grid, dim3(256), 0, st, p);
 }
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
   dim3 grid((p.R + BM - 1) / BM, (p.O + BN - 1) / BN, p.groups * p.splitk);
-  if (p.K % 32 == 0 && p.splitk == 1) launch_bk<32>(p, a_kouter, b_kouter, grid, st);
-  else launch_bk<16>(p, a_kouter, b_kouter, grid, st);
+  const bool bk32 = (p.K % 32 == 0 && p.splitk == 1);
+  if (p.bf16 == 2) {
+    if (bk32) launch_bk<32, 2>(p, a_kouter, b_kouter, grid, st);
+    else launch_bk<16, 2>(p, a_kouter, b_kouter, grid, st);
+  } else if (p.bf16 == 1) {
+    if (bk32) launch_bk<32, 1>(p, a_kouter, b_kouter, grid, st);
+    else launch_bk<16, 1>(p, a_kouter, b_kouter, grid, st);
+  } else {
+    if (bk32) launch_bk<32, 0>(p, a_kouter, b_kouter, grid, st);
+    else launch_bk<16, 0>(p, a_kouter, b_kouter, grid, st);
+  }
 }

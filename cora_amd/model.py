@@ -136,13 +136,17 @@ class GradView:
 class TransformerDecoder:
     """Same constructor and attribute layout as the reference model; state lives on the GPU."""
 
-    def __init__(self, config: TransformerConfig, *, seed: int = 42, device: int = 0, max_T: int = 64):
+    def __init__(self, config: TransformerConfig, *, seed: int = 42, device: int = 0, max_T: int = 64,
+                 compute_dtype: str = "fp32"):
         _lib.load()                      # fail loudly if the HIP library is missing
         if config.update_weights_every_inference_step:
             raise NotImplementedError("iPC mode (update_weights_every_inference_step=True) is outside "
                                       "the implemented hot path (SURVEY 8(f) rank 4)")
         if config.use_vode_state_layernorm:
             raise NotImplementedError("use_vode_state_layernorm is outside the implemented hot path")
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' (parity path) or 'bf16' (opt-in: bf16 MFMA operands)")
+        self._dtype_mode = 1 if compute_dtype == "bf16" else 0
         self.config = config
         self.device = device
         self.max_T = max_T
@@ -190,7 +194,7 @@ class TransformerDecoder:
         c = self.config
         return _lib.CoraConfig(
             N=self.N, P=self.P, D=self.D, H=self.H, M=self.M, L=self.L, B=B, C=self._C,
-            patch=c.patch_size, Himg=self._Himg, Wimg=self._Wimg, F=self._F, dtype_mode=0,
+            patch=c.patch_size, Himg=self._Himg, Wimg=self._Wimg, F=self._F, dtype_mode=self._dtype_mode,
             use_scaling=int(bool(c.use_inference_lr_scaling)),
             scale_base=float(c.inference_lr_scale_base if c.inference_lr_scale_base is not None else 1.0),
             l1=float(c.intermediate_l1_coeff), l2=float(c.intermediate_l2_coeff),

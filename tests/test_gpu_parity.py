@@ -98,6 +98,37 @@ def test_regularisers_and_clipping():
     run_case("tiny_2block_h2", l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5)
 
 
+BF16_TOL = 1e-2
+
+
+@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1"])
+def test_bf16_opt_in(name):
+    """Opt-in bf16 mode (BASELINE.json north_star: "bf16 as an opt-in mode", bar rel <= 1e-2 on final
+    vodes, per-step energies and weight gradients; configs[3] names bf16 MFMA for the 224x224 case):
+    GEMM operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16, accumulation and
+    every stored tensor stay fp32.  Gradients are compared per tensor against the largest entry of
+    that tensor family, as in the fp32 test."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = CASES[name]
+    case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000)
+    model, optim_w, optim_h = build_model(case, compute_dtype="bf16")
+    eta = [0.095] * T
+    ref = R.train_on_batch(T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], eta, 1e-3)
+    Eh, Ew, gh, gw, mse = ca.train_on_batch(T, case["x"], model=model, optim_w=optim_w, optim_h=optim_h)
+    tot, per = ca.step_energies(model, T)
+    errs = {"energies": relerr(tot, ref["energies"]), "final_w_energy": relerr(Ew, ref["final_w_energy"]),
+            "train_mse": relerr(mse, ref["train_mse"])}
+    for l in range(L + 2):
+        errs[f"h{l}"] = relerr(model.vodes[l].h.get(), ref["h"][l])
+    gnorm = max(np.abs(v).max() for v in ref["w_grad"].values())
+    for k, v in ref["w_grad"].items():
+        errs["gw" + k] = float(np.abs(gw[k].astype(np.float64) - v).max() / gnorm)
+    model.close()
+    print(name, "bf16 max rel err", max(errs.values()), max(errs, key=errs.get))
+    bad = {k: v for k, v in errs.items() if not v <= BF16_TOL}
+    assert not bad, f"{name}: bf16 parity failures: {bad}"
+
+
 @pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4"])
 def test_vode_grad_norm_option(name):
     # normalize_vode_h_gradients (src/decoder_transformer.py:353-389): per-leaf g / (||g|| + 1e-8) * target,

@@ -26,7 +26,7 @@ def make_case(image_shape, patch, D, H, L, B, seed=0, l1=0.0, l2=0.0, clip_h=200
     return dict(dims=dims, W=W, pos=pos, x=x, h=h, hp=hp, h0=h0)
 
 
-def build_model(case, max_T=64):
+def build_model(case, max_T=64, compute_dtype="fp32"):
     import cora_amd as ca
     d, hp = case["dims"], case["hp"]
     cfg = ca.TransformerConfig(
@@ -36,7 +36,7 @@ def build_model(case, max_T=64):
         use_status_init_in_training=False, use_status_init_in_unmasking=False,
         intermediate_l1_coeff=hp.l1, intermediate_l2_coeff=hp.l2,
         use_vode_grad_norm=hp.use_grad_norm, vode_grad_norm_target=hp.grad_norm_target)
-    model = ca.TransformerDecoder(cfg, max_T=max_T)
+    model = ca.TransformerDecoder(cfg, max_T=max_T, compute_dtype=compute_dtype)
     model.positional_embedding = case["pos"]
     model.set_weights(case["W"])
     B = case["x"].shape[0]
