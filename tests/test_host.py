@@ -118,7 +118,7 @@ def test_create_fails_loudly_without_gpu_or_on_bad_config():
     import ctypes as C
     import torch
     lib = _lib.load()
-    cfg = _lib.CoraConfig(N=4, P=48, D=16, H=1, M=64, L=1, B=2, C=3, patch=4, Himg=8, Wimg=8, F=1, dtype_mode=1)
+    cfg = _lib.CoraConfig(N=4, P=48, D=16, H=1, M=64, L=1, B=2, C=3, patch=4, Himg=8, Wimg=8, F=1, dtype_mode=7)
     ctx = C.c_void_p()
     assert lib.cora_create(C.byref(cfg), 0, C.byref(ctx)) != 0
     assert b"dtype_mode" in lib.cora_last_error(None)
