@@ -169,11 +169,14 @@ struct FusedP {
   // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
   float *S_xn1, *S_att, *S_xn2, *S_a, *S_da, *S_dy, *S_dqkv;
   float* S_stash;   // [L*B*N, 3D]: q | P | y parked between forward and backward
-  float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients are accumulated here (null otherwise)
+  float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients land here (null otherwise)
+  float* colpart;   // MODE_STORE: per-wave column sums of the block workgroups (fused_colpart_floats)
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error
   float* Z; double* mse;
   unsigned long long* dbg;   // diagnostic builds only (-DCORA_STAMPS)
 };
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
 int launch_chain(const FusedP& p, int store_h, hipStream_t st);
+void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
+size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

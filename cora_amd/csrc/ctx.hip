@@ -67,6 +67,7 @@ struct cora_ctx {
   // inpainting loop (cora_unmask): ground truth and mask in patch layout, momentum of the un-frozen
   // sensory vode (allocated on first use); sens_live marks the sensory vode as un-frozen
   float *xt = nullptr, *mk = nullptr, *msens = nullptr;
+  float* colpart = nullptr;    // fused STORE pass: per-wave column sums (bias / LayerNorm gradients)
   bool sens_live = false;
   float sens_scale = 1.f;
   double* energies = nullptr;  // [(Tmax+2), L+3]
@@ -546,6 +547,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
     c->nWT = t;
     DA(c->WT, c->nWT);
+    DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
@@ -833,9 +835,10 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     // weight-gradient contractions need; its vode-gradient outputs go to scratch (final_h_grad stays)
     FusedP f;
     fill_fused(c, f, c->energies + (long long)slot * (L + 3), c->sumsq + (long long)(c->Tmax + 1) * (L + 2) * 8);
-    f.BP1 = c->qkv; f.G0 = c->ua; f.dW = c->dW;
+    f.BP1 = c->qkv; f.G0 = c->ua; f.dW = c->dW; f.colpart = c->colpart;
     KScope s(c, K_FUSED, block_step_flops(c), 0);
     if (launch_fused_block(f, L, 1, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
+    launch_colpart_reduce(f, L, c->st);
   } else {
     rc = errors_pass(c, slot);   // learning_step_fn evaluates E at the final vodes, :482-483
     if (rc) return rc;

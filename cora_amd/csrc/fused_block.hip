@@ -98,10 +98,14 @@ __device__ __forceinline__ void store_rowT(const float* f, float* base, int grp)
     *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
 }
 
-// column sums over the 16 rows of a wave (lanes with equal grp), added to dst[16 ct + 4 grp + reg]:
-// bias / LayerNorm-parameter gradients of the weight step (dE/dtheta = -sum_rows ...)
+// Bias / LayerNorm-parameter gradients (dE/dtheta = -sum_rows ...): column sums over the 16 rows of
+// a wave (lanes with equal grp).  The workgroups do not add into dW directly (800 waves per
+// address: the float atomics doubled the STORE pass): each wave leaves its sums in its own slice of a scratch
+// table, colpart[(g * B + b) * 4 + w][COLPART], reduced over the 4 B slices by colpart_reduce_kernel.
+constexpr int CP_B2 = 0, CP_B1 = 64, CP_LN2B = 320, CP_LN2G = 384, CP_LN1B = 448, CP_LN1G = 512, COLPART = 576;
+constexpr int CP_EDGE = 128;   // edge workgroups: [bp 64 | bout 48 | pad], table appended after the block slices
 template <int NCT>
-__device__ __forceinline__ void colsum_atomic(const float* f, float* dst, float alpha, int i, int grp) {
+__device__ __forceinline__ void colsum_store(const float* f, float* dst, int i, int grp) {
 #pragma unroll
   for (int k = 0; k < 4 * NCT; ++k) {
     float v = f[k];
@@ -109,7 +113,7 @@ __device__ __forceinline__ void colsum_atomic(const float* f, float* dst, float 
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
-    if (i == 0) atomicAdd(&dst[16 * (k >> 2) + 4 * grp + (k & 3)], alpha * v);
+    if (i == 0) dst[16 * (k >> 2) + 4 * grp + (k & 3)] = v;
   }
 }
 
@@ -202,7 +206,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
       en += 0.5f * e1[k] * e1[k] + p.l1 * fabsf(h1[k]) + p.l2 * h1[k] * h1[k];
     }
     store_rowT_n<4>(e1, p.E1 + tok * D, grp);
-    if (p.dW) colsum_atomic<4>(e1, p.dW + p.obp, -1.f, i, grp);
+    if (p.dW) colsum_store<4>(e1, p.colpart + (long long)p.L * p.B * 4 * COLPART + ((long long)b * 4 + w) * CP_EDGE, i, grp);
     double tot = wave_sum_d((double)en);
     if (p.energy && lane == 0) atomicAdd(&p.energy[-1], tot);   // energy[] points at vode 2; vode 1 is [-1]
   }
@@ -229,7 +233,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float e = xp[4 * k + j] - (acc[k][j] + bo[4 * k + j]); ei[4 * k + j] = e; en += 0.5f * e * e; }
     store_rowT_n<3>(ei, p.EIMG + tok * P, grp);
-    if (p.dW) colsum_atomic<3>(ei, p.dW + p.obout, -1.f, i, grp);
+    if (p.dW) colsum_store<3>(ei, p.colpart + (long long)p.L * p.B * 4 * COLPART + ((long long)b * 4 + w) * CP_EDGE + 64, i, grp);
     double tot = wave_sum_d((double)en);
     if (lane == 0) {                                         // vode L+2 (sensory)
       if (p.energy) atomicAdd(&p.energy[p.L], tot);
@@ -294,6 +298,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const float* xrow = p.H1 + voff;
   const float* hnext = p.H1 + voff + nl;
   const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
+  float* cpart = (MODE == MODE_STORE) ? p.colpart + (((long long)g * p.B + b) * 4 + w) * COLPART : nullptr;
   // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
   // in the forward and only needed again in the backward (q, P, y, the MLP pre-activation a) are
   // parked in an L2-resident stash instead of registers and reloaded at their point of use.
@@ -495,7 +500,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     store_rowT(r, p.E2 + (long long)g * nl + rowoff, grp);
     double tot = wave_sum_d((double)en);
     if (MODE == MODE_STORE && lane == 0) atomicAdd(&p.energy[g], tot);
-    if (MODE == MODE_STORE) colsum_atomic<4>(r, p.dW + p.ob2 + (long long)g * D, -1.f, i, grp);
+    if (MODE == MODE_STORE) colsum_store<4>(r, cpart + CP_B2, i, grp);
   }
 
   STAMP(6);
@@ -524,7 +529,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       for (int k = 0; k < 16; ++k) dg[k] *= cora_gelu_grad(am[k]);
       if (MODE == MODE_STORE) {
         store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
-        colsum_atomic<4>(dg, p.dW + p.ob1 + (long long)g * M + 64 * mt, -1.f, i, grp);
+        colsum_store<4>(dg, cpart + CP_B1 + 64 * mt, i, grp);
       }
       if (mt < 2) SUB(5 + 6 * mt);
       PUBLISH(1, t);                                        // tile 13+2mt: W1^T[:, mt]
@@ -547,10 +552,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     for (int k = 0; k < 16; ++k) dy[k] += r[k];
     if (MODE == MODE_STORE) {
       store_rowT(dy, p.S_dy + srow_g * D, grp);
-      colsum_atomic<4>(dzn, p.dW + p.oLn2b + (long long)g * D, -1.f, i, grp);
+      colsum_store<4>(dzn, cpart + CP_LN2B, i, grp);
 #pragma unroll
       for (int k = 0; k < 16; ++k) dzn[k] *= xh[k];
-      colsum_atomic<4>(dzn, p.dW + p.oLn2g + (long long)g * D, -1.f, i, grp);
+      colsum_store<4>(dzn, cpart + CP_LN2G, i, grp);
     }
   }
   STAMP(8);
@@ -634,10 +639,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     ln_rowT(xv, gm, bt, xh, tmp);
     ln_bwd_rowT(dxn, gm, xh, dk);
     if (MODE == MODE_STORE) {
-      colsum_atomic<4>(dxn, p.dW + p.oLn1b + (long long)g * D, -1.f, i, grp);
+      colsum_store<4>(dxn, cpart + CP_LN1B, i, grp);
 #pragma unroll
       for (int k = 0; k < 16; ++k) dxn[k] *= xh[k];
-      colsum_atomic<4>(dxn, p.dW + p.oLn1g + (long long)g * D, -1.f, i, grp);
+      colsum_store<4>(dxn, cpart + CP_LN1G, i, grp);
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) dk[k] += r[k];        // r holds r + dy
@@ -759,3 +764,39 @@ void launch_transpose(const float* src, float* dst, int rows, int cols, int grou
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, groups);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, src, dst, rows, cols);
 }
+
+// ---- dW[bias / LayerNorm parameters] -= sum over the 4 B wave slices of colpart (dW zeroed before) ------------
+// grid (L + 1, COLPART / 64, row chunks): group L is the edge table (patch / output projection biases)
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(FusedP p) {
+  __shared__ float sh[4][64];
+  const int g = blockIdx.x, c0 = 64 * blockIdx.y;
+  const bool edge = (g == p.L);
+  if (edge && c0 >= CP_EDGE) return;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int stride = edge ? CP_EDGE : COLPART;
+  const float* src = p.colpart + (edge ? (long long)p.L * p.B * 4 * COLPART : (long long)g * p.B * 4 * COLPART) + c0 + cx;
+  const int rows = 4 * p.B, per = (rows + gridDim.z - 1) / gridDim.z;
+  const int r0 = blockIdx.z * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  for (int rr = r0 + ry; rr < r1; rr += 4) s += src[(long long)rr * stride];
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0) {
+    s = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+    long long off;
+    if (edge) {
+      if (c0 == 0) off = p.obp; else { if (cx >= 48) return; off = p.obout; }
+    }
+    else if (c0 < CP_B1) off = p.ob2 + (long long)g * 64;
+    else if (c0 < CP_LN2B) off = p.ob1 + (long long)g * 256 + (c0 - CP_B1);
+    else if (c0 < CP_LN2G) off = p.oLn2b + (long long)g * 64;
+    else if (c0 < CP_LN1B) off = p.oLn2g + (long long)g * 64;
+    else if (c0 < CP_LN1G) off = p.oLn1b + (long long)g * 64;
+    else off = p.oLn1g + (long long)g * 64;
+    atomicAdd(&p.dW[off + cx], -s);
+  }
+}
+void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st) {
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(L + 1, COLPART / 64, 16), dim3(256), 0, st, p);
+}
+size_t fused_colpart_floats(int L, int B) { return (size_t)L * B * 4 * COLPART + (size_t)B * 4 * CP_EDGE; }
