@@ -225,6 +225,13 @@ def main():
             "whole_step_mfma_frac": (value * S / 1e12) / (PEAK_FP32_MATRIX_TFLOPS * world),
             "roofline": roof,
             "kernel_ms_per_inference_step": {k: v["ms"] / reps for k, v in kinds.items()},
+            # bandwidth-bound kernels of the step (energy + gradient finish, clip + momentum update):
+            # algorithmic bytes / measured launch time, against the HBM peak
+            "hbm_kernels": {k: {"achieved_GBs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "bytes_per_launch": v["bytes"] / v["launches"],
+                                "avg_launch_us": 1e3 * v["ms"] / v["launches"]}
+                            for k, v in kinds.items() if v["flops"] == 0 and v["bytes"] > 0},
             "inference_step_kernel_ms_total": step_ms_kernels,
         }
     if dist is not None:
