@@ -244,18 +244,31 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   __syncthreads();
   const float eta = p.eta[p.t];
   const long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    long long e = 4 * i;
-    int l = (e < p.n0) ? 0 : 1 + (int)((e - p.n0) / p.nl);
-    float mul = mult_sh[l];
-    float4 g = *reinterpret_cast<const float4*>(p.g + e);
-    float4 m = *reinterpret_cast<const float4*>(p.m + e);
-    float4 h = *reinterpret_cast<const float4*>(p.h + e);
-    m.x = g.x * mul + p.mu * m.x; m.y = g.y * mul + p.mu * m.y;
-    m.z = g.z * mul + p.mu * m.z; m.w = g.w * mul + p.mu * m.w;
-    h.x -= eta * m.x; h.y -= eta * m.y; h.z -= eta * m.z; h.w -= eta * m.w;
-    *reinterpret_cast<float4*>(p.m + e) = m;
-    *reinterpret_cast<float4*>(p.h + e) = h;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  constexpr int NS = 2;   // independent float4 triples in flight per thread
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += NS * stride) {
+    float4 g[NS], m[NS], h[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const long long e = 4 * (i0 + u * stride);
+      if (i0 + u * stride < n4) {
+        g[u] = *reinterpret_cast<const float4*>(p.g + e);
+        m[u] = *reinterpret_cast<const float4*>(p.m + e);
+        h[u] = *reinterpret_cast<const float4*>(p.h + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      if (i0 + u * stride >= n4) break;
+      const long long e = 4 * (i0 + u * stride);
+      const int l = (e < p.n0) ? 0 : 1 + (int)((e - p.n0) / p.nl);
+      const float mul = mult_sh[l];
+      m[u].x = g[u].x * mul + p.mu * m[u].x; m[u].y = g[u].y * mul + p.mu * m[u].y;
+      m[u].z = g[u].z * mul + p.mu * m[u].z; m[u].w = g[u].w * mul + p.mu * m[u].w;
+      h[u].x -= eta * m[u].x; h[u].y -= eta * m[u].y; h[u].z -= eta * m[u].z; h[u].w -= eta * m[u].w;
+      *reinterpret_cast<float4*>(p.m + e) = m[u];
+      *reinterpret_cast<float4*>(p.h + e) = h[u];
+    }
   }
 }
 __global__ __launch_bounds__(256) void sens_update_kernel(UpdateP p, float* __restrict__ hs, float* __restrict__ ms,
@@ -322,18 +335,19 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
   double ss = 0.0;
   float en = 0.f;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  // two independent float4 streams per thread and iteration: enough loads in flight to run at
-  // the memory rate with the 8 waves per SIMD this kernel gets
-  for (long long k0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; k0 < nl4; k0 += 2 * stride) {
-    const long long k1 = k0 + stride;
-    const bool two = k1 < nl4;
-    float4 bq[2], eq[2], hq[2];
-    bq[0] = bpp[k0]; eq[0] = ep[k0];
-    if (two) { bq[1] = bpp[k1]; eq[1] = ep[k1]; }
-    if (reg) { hq[0] = hp[k0]; if (two) hq[1] = hp[k1]; }
+  // NS independent float4 streams per thread and iteration keep enough loads in flight
+  constexpr int NS = 4;
+  for (long long k0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; k0 < nl4; k0 += NS * stride) {
+    float4 bq[NS], eq[NS], hq[NS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !two) break;
+    for (int u = 0; u < NS; ++u) {
+      const long long k = k0 + u * stride;
+      if (k < nl4) { bq[u] = bpp[k]; eq[u] = ep[k]; if (reg) hq[u] = hp[k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const long long k = k0 + u * stride;
+      if (k >= nl4) break;
       float bp[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w}, e[4] = {eq[u].x, eq[u].y, eq[u].z, eq[u].w}, o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { o[j] = e[j]; en += 0.5f * e[j] * e[j]; }
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
         }
       }
       float4 gv = make_float4(s * (o[0] - bp[0]), s * (o[1] - bp[1]), s * (o[2] - bp[2]), s * (o[3] - bp[3]));
-      gp[u == 0 ? k0 : k1] = gv;
+      gp[k] = gv;
       ss += (double)(gv.x * gv.x + gv.y * gv.y) + (double)(gv.z * gv.z + gv.w * gv.w);
     }
   }
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
 }
 void launch_vode_grad(const VodeGradP& p, hipStream_t st) {
   long long nl4 = p.nl / 4;
-  long long bx = (nl4 + 511) / 512;     // two float4 per thread and iteration
+  long long bx = (nl4 + 1023) / 1024;   // four float4 per thread and iteration
   if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(vode_grad_kernel, dim3((unsigned)bx, p.nlay), dim3(256), 0, st, p);
