@@ -147,6 +147,7 @@ void launch_sumsq(const float* a, long long n, float scale, double* out, hipStre
 struct AdamP {
   float* w; const float* g; float* mu; float* nu; long long n;
   const double* sumsq; float gscale, clip, lr, b1, b2, eps, wd; float bc1, bc2;
+  const float* hyp;   // if set: {lr, bc1, bc2} read from device memory (the captured learning graph)
 };
 void launch_adamw(const AdamP& p, hipStream_t st);
 // red[0] += sum (clip01(a)-clip01(b))^2

@@ -77,6 +77,11 @@ struct cora_ctx {
   float scale_l[64];
 
   std::map<int, hipGraphExec_t> graphs;
+  bool learn_warm = false;
+  hipGraphExec_t learn_graph = nullptr;   // cora_step: weight gradients + AdamW + reconstruction, captured once
+  float* hyp_dev = nullptr;               // {eta_w, 1 - b1^count, 1 - b2^count} for the captured AdamW
+  double* host_out = nullptr;             // pinned: scalars read back at the end of cora_step
+  hipEvent_t ev2 = nullptr;
   bool use_graph = true;
   bool warmed = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -526,7 +531,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->use_graph = getenv("CORA_NO_GRAPH") == nullptr;
   auto fail = [&](int rc) { g_create_err = c->err; cora_destroy(c); return rc; };
   if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(-2); }
-  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1); hipEventCreate(&c->ev2);
 
   const size_t D = c->D, P = c->P, M = c->M, L = c->L;
   size_t o = 0;
@@ -566,6 +571,9 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 3)); c->esum = (double*)tmp;
   DA(tmp, 8); c->scal = (double*)tmp;
+  DA(c->hyp_dev, 4);
+  if (hipHostMalloc((void**)&c->host_out, sizeof(double) * ((size_t)(L + 3) * 9 + 8), hipHostMallocDefault) != hipSuccess)
+    return fail(-2);
 #undef DA
   // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
   float gs[64];
@@ -593,9 +601,12 @@ int cora_destroy(cora_ctx* c) {
   hipSetDevice(c->device);
   if (c->st) hipStreamSynchronize(c->st);
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+  if (c->learn_graph) hipGraphExecDestroy(c->learn_graph);
   for (void* p : c->allocs) hipFree(p);
+  if (c->host_out) hipHostFree(c->host_out);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->ev2) hipEventDestroy(c->ev2);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
   return 0;
@@ -761,6 +772,7 @@ int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, floa
   if (!c) return -1;
   cora_config& f = c->cfg;
   bool graph_dirty = (f.clip_h != clip_h) || (f.momentum != momentum);
+  bool learn_dirty = (f.clip_w != clip_w) || (f.adam_b1 != b1) || (f.adam_b2 != b2) || (f.adam_eps != eps) || (f.adam_wd != wd);
   f.clip_h = clip_h; f.momentum = momentum; f.clip_w = clip_w;
   f.adam_b1 = b1; f.adam_b2 = b2; f.adam_eps = eps; f.adam_wd = wd;
   if (graph_dirty) {
@@ -769,8 +781,16 @@ int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, floa
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
   }
+  if (learn_dirty && c->learn_graph) {
+    HCHECK(hipSetDevice(c->device));
+    HCHECK(hipStreamSynchronize(c->st));
+    hipGraphExecDestroy(c->learn_graph);
+    c->learn_graph = nullptr;
+  }
   return 0;
 }
+
+int infer_graph(cora_ctx* c, int T, hipGraphExec_t* out);
 
 int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, cora_step_out* out) {
   if (!c) return -1;
@@ -788,22 +808,10 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
     if (rc) return rc;
     HCHECK(hipEventRecord(c->ev1, c->st));
   } else {
-    auto it = c->graphs.find(T);
-    if (it == c->graphs.end()) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
-      rc = enqueue_infer(c, T);
-      hipError_t e = hipStreamEndCapture(c->st, &graph);
-      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
-      HCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
-      c->graphs[T] = exec;
-      it = c->graphs.find(T);
-    }
+    hipGraphExec_t gi = nullptr;
+    if ((rc = infer_graph(c, T, &gi))) return rc;
     HCHECK(hipEventRecord(c->ev0, c->st));
-    HCHECK(hipGraphLaunch(it->second, c->st));
+    HCHECK(hipGraphLaunch(gi, c->st));
     HCHECK(hipEventRecord(c->ev1, c->st));
   }
   HCHECK(hipStreamSynchronize(c->st));
@@ -820,15 +828,13 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
   return 0;
 }
 
-int cora_wgrad(cora_ctx* c, cora_step_out* out) {
-  if (!c) return -1;
-  HCHECK(hipSetDevice(c->device));
+// weight gradients at the final vodes (:482-483) into dW; no synchronisation, capturable
+int enqueue_wgrad(cora_ctx* c) {
   const int L = c->L, D = c->D, M = c->M, P = c->P;
   const int R = (int)c->BN;
   const int slot = c->Tmax;
-  HCHECK(hipEventRecord(c->ev0, c->st));
-  HCHECK(hipMemsetAsync(c->energies + (long long)slot * (L + 3), 0, sizeof(double) * (L + 3), c->st));
-  HCHECK(hipMemsetAsync(c->dW, 0, sizeof(float) * c->nW, c->st));
+  launch_zero(c->energies + (long long)slot * (L + 3), (sizeof(double) * (L + 3) + 15) / 16 * 16, c->st);
+  launch_zero(c->dW, (sizeof(float) * c->nW + 15) / 16 * 16, c->st);
   int rc = 0;
   if (c->fused) {
     // one fused launch evaluates E at the final vodes (:482-483) and leaves every tensor the
@@ -860,7 +866,7 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     wgrad_gemm(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);  // dW1 = -da^T LN2(y)
     wgrad_gemm(c, L, c->dy, D, sD, c->att, D, sD, c->dW + c->oWo, (long long)D * D, 0);  // dWo = -dy^T att
     wgrad_gemm(c, L, c->dqkv, 3 * D, s3, c->xn1, D, sD, c->dW + c->oWqkv, 3LL * D * D, 0);
-    if (!c->fused) {   // the fused STORE kernel accumulates these column sums itself
+    if (!c->fused) {   // the fused STORE kernel leaves these column sums itself
       KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
       launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
       launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
@@ -870,6 +876,45 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
       launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
     }
   }
+  return 0;
+}
+
+// clip + AdamW on dW (scaled by scale_by), transposes for the fused kernel, reconstruction with the
+// updated weights and its clipped MSE (:484-494).  eta_w and the bias corrections come from
+// c->hyp_dev so the sequence can sit in a captured graph.  No synchronisation.
+int enqueue_apply(cora_ctx* c, float scale_by) {
+  launch_zero(c->scal, 32, c->st);
+  { KScope s(c, K_OTHER, 0, 4.0 * c->nW); launch_sumsq(c->dW, (long long)c->nW, scale_by, c->scal, c->st); }
+  AdamP a; memset(&a, 0, sizeof a);
+  a.w = c->W; a.g = c->dW; a.mu = c->amu; a.nu = c->anu; a.n = (long long)c->nW; a.sumsq = c->scal;
+  a.gscale = scale_by; a.clip = c->cfg.clip_w; a.b1 = c->cfg.adam_b1; a.b2 = c->cfg.adam_b2;
+  a.eps = c->cfg.adam_eps; a.wd = c->cfg.adam_wd; a.hyp = c->hyp_dev;
+  { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
+  refresh_wt(c);
+  // reconstruction under status "forward" with the updated weights, :488-494
+  int rc = chain_forward(c, false, c->scal + 1);
+  if (rc) return rc;
+  if (!c->fused) { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
+  return 0;
+}
+
+// host side of one AdamW step: advance the count and stage {eta_w, 1 - b1^count, 1 - b2^count}
+int stage_adam_hyp(cora_ctx* c, float eta_w) {
+  c->adam_count += 1;
+  float h[4] = {eta_w, (float)(1.0 - pow((double)c->cfg.adam_b1, (double)c->adam_count)),
+                (float)(1.0 - pow((double)c->cfg.adam_b2, (double)c->adam_count)), 0.f};
+  HCHECK(hipMemcpyAsync(c->hyp_dev, h, sizeof h, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));   // h is a stack buffer
+  return 0;
+}
+
+int cora_wgrad(cora_ctx* c, cora_step_out* out) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L, slot = c->Tmax;
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  int rc = enqueue_wgrad(c);
+  if (rc) return rc;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {
@@ -888,22 +933,11 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
 int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* out) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
-  HCHECK(hipEventRecord(c->ev0, c->st));
-  HCHECK(hipMemsetAsync(c->scal, 0, sizeof(double) * 4, c->st));
-  { KScope s(c, K_OTHER, 0, 4.0 * c->nW); launch_sumsq(c->dW, (long long)c->nW, scale_by, c->scal, c->st); }
-  c->adam_count += 1;
-  AdamP a; memset(&a, 0, sizeof a);
-  a.w = c->W; a.g = c->dW; a.mu = c->amu; a.nu = c->anu; a.n = (long long)c->nW; a.sumsq = c->scal;
-  a.gscale = scale_by; a.clip = c->cfg.clip_w; a.lr = eta_w; a.b1 = c->cfg.adam_b1; a.b2 = c->cfg.adam_b2;
-  a.eps = c->cfg.adam_eps; a.wd = c->cfg.adam_wd;
-  a.bc1 = (float)(1.0 - pow((double)a.b1, (double)c->adam_count));
-  a.bc2 = (float)(1.0 - pow((double)a.b2, (double)c->adam_count));
-  { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
-  refresh_wt(c);
-  // reconstruction under status "forward" with the updated weights, :488-494
-  int rc = chain_forward(c, false, c->scal + 1);
+  int rc = stage_adam_hyp(c, eta_w);
   if (rc) return rc;
-  if (!c->fused) { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  rc = enqueue_apply(c, scale_by);
+  if (rc) return rc;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {
@@ -917,16 +951,87 @@ int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* ou
   return 0;
 }
 
+// instantiate (once per T) the captured inference loop
+int infer_graph(cora_ctx* c, int T, hipGraphExec_t* out) {
+  auto it = c->graphs.find(T);
+  if (it == c->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_infer(c, T);
+    hipError_t e = hipStreamEndCapture(c->st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+    HCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    c->graphs[T] = exec;
+    it = c->graphs.find(T);
+  }
+  *out = it->second;
+  return 0;
+}
+
 int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, float eta_w, cora_step_out* out) {
   if (!c) return -1;
-  cora_step_out tmp; memset(&tmp, 0, sizeof tmp);
-  int rc = cora_infer(c, x, x_on_device, T, eta_h, &tmp);
+  if (!c->use_graph || c->prof || !c->learn_warm) {   // eager: the three public phases back to back
+    c->learn_warm = true;   // every learning-phase kernel has run once outside stream capture after this
+    cora_step_out tmp; memset(&tmp, 0, sizeof tmp);
+    int rc = cora_infer(c, x, x_on_device, T, eta_h, &tmp);
+    if (rc) return rc;
+    rc = cora_wgrad(c, &tmp);
+    if (rc) return rc;
+    rc = cora_apply_wgrad(c, eta_w, 1.0f / (float)c->B, &tmp);
+    if (rc) return rc;
+    if (out) *out = tmp;
+    return 0;
+  }
+  // Two graph launches and ONE host synchronisation per batch: the inference loop (per-T graph) and
+  // the learning phase (weight gradients, clip + AdamW, transposes, reconstruction).
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!eta_h) FAIL(-1, "eta_h is NULL");
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L;
+  int rc = upload_x(c, x, x_on_device);
   if (rc) return rc;
-  rc = cora_wgrad(c, &tmp);
-  if (rc) return rc;
-  rc = cora_apply_wgrad(c, eta_w, 1.0f / (float)c->B, &tmp);
-  if (rc) return rc;
-  if (out) *out = tmp;
+  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  if ((rc = stage_adam_hyp(c, eta_w))) return rc;   // also synchronises: x / eta_h are caller-owned
+  c->last_T = T;
+  hipGraphExec_t gi = nullptr;
+  if ((rc = infer_graph(c, T, &gi))) return rc;
+  if (!c->learn_graph) {
+    hipGraph_t graph = nullptr;
+    HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_wgrad(c);
+    if (!rc) rc = enqueue_apply(c, 1.0f / (float)c->B);
+    hipError_t e = hipStreamEndCapture(c->st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+    HCHECK(hipGraphInstantiate(&c->learn_graph, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+  }
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  HCHECK(hipGraphLaunch(gi, c->st));
+  HCHECK(hipEventRecord(c->ev1, c->st));
+  HCHECK(hipGraphLaunch(c->learn_graph, c->st));
+  HCHECK(hipEventRecord(c->ev2, c->st));
+  // scalars back through pinned memory: [energy row of step T-1 (slots or plain)] [w-energy row] [mse sum]
+  double* ho = c->host_out;
+  const size_t nslot = (size_t)(L + 3) * 8;
+  if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+  else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
+    hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
+    double eh = 0.0, ew = 0.0;
+    for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+    for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
+    out->final_h_energy = eh; out->final_w_energy = ew;
+    out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;
+  }
   return 0;
 }
 
@@ -939,6 +1044,7 @@ int cora_bind_wgrad_buffer(cora_ctx* c, void* dev, size_t n) {
   if (!c) return -1;
   if (!dev || n != c->nW) FAIL(-1, "bind_wgrad_buffer: size mismatch");
   if (((uintptr_t)dev) % 16) FAIL(-1, "bind_wgrad_buffer: pointer must be 16-byte aligned");
+  if (c->learn_graph) { hipStreamSynchronize(c->st); hipGraphExecDestroy(c->learn_graph); c->learn_graph = nullptr; }
   c->dW = (float*)dev;   // the old buffer stays in c->allocs and is freed with the ctx
   c->dW_owned = false;
   return 0;

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP p) {
     if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
   }
   const float gmul = p.gscale * cm;
+  if (p.hyp) { p.lr = p.hyp[0]; p.bc1 = p.hyp[1]; p.bc2 = p.hyp[2]; }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) {
     float g = p.g[i] * gmul;
     float mu = p.b1 * p.mu[i] + (1.f - p.b1) * g;
