@@ -78,7 +78,10 @@ struct cora_ctx {
 
   std::map<int, hipGraphExec_t> graphs;
   bool learn_warm = false;
-  hipGraphExec_t learn_graph = nullptr;   // cora_step: weight gradients + AdamW + reconstruction, captured once
+  hipGraphExec_t learn_graph = nullptr;
+  // data-parallel path: the two halves around the all-reduce, captured separately
+  hipGraphExec_t wgrad_graph = nullptr, apply_graph = nullptr;
+  float apply_graph_scale = 0.f;   // cora_step: weight gradients + AdamW + reconstruction, captured once
   float* hyp_dev = nullptr;               // {eta_w, 1 - b1^count, 1 - b2^count} for the captured AdamW
   double* host_out = nullptr;             // pinned: scalars read back at the end of cora_step
   hipEvent_t ev2 = nullptr;
@@ -135,6 +138,13 @@ int dalloc(cora_ctx* c, float** p, long long n) {
 
 float* vode_ptr(cora_ctx* c, float* base, int l) { return l == 0 ? base : base + c->n0 + (long long)(l - 1) * c->nl; }
 float* err_ptr(cora_ctx* c, int l) { return c->Es + (long long)(l - 1) * c->nl; }  // l = 1..L+1 ; L+2 = e_img
+
+void drop_learn_graphs(cora_ctx* c) {
+  if (c->learn_graph || c->wgrad_graph || c->apply_graph) hipStreamSynchronize(c->st);
+  if (c->learn_graph) { hipGraphExecDestroy(c->learn_graph); c->learn_graph = nullptr; }
+  if (c->wgrad_graph) { hipGraphExecDestroy(c->wgrad_graph); c->wgrad_graph = nullptr; }
+  if (c->apply_graph) { hipGraphExecDestroy(c->apply_graph); c->apply_graph = nullptr; }
+}
 
 GemmP gemm_base(cora_ctx* c, int kind = 0 /* 0 forward, 1 backward-data, 2 weight-gradient */) {
   GemmP p;
@@ -601,7 +611,7 @@ int cora_destroy(cora_ctx* c) {
   hipSetDevice(c->device);
   if (c->st) hipStreamSynchronize(c->st);
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-  if (c->learn_graph) hipGraphExecDestroy(c->learn_graph);
+  drop_learn_graphs(c);
   for (void* p : c->allocs) hipFree(p);
   if (c->host_out) hipHostFree(c->host_out);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -781,11 +791,9 @@ int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, floa
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
   }
-  if (learn_dirty && c->learn_graph) {
+  if (learn_dirty) {
     HCHECK(hipSetDevice(c->device));
-    HCHECK(hipStreamSynchronize(c->st));
-    hipGraphExecDestroy(c->learn_graph);
-    c->learn_graph = nullptr;
+    drop_learn_graphs(c);
   }
   return 0;
 }
@@ -912,9 +920,21 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
   const int L = c->L, slot = c->Tmax;
+  int rc = 0;
+  const bool graphed = c->use_graph && !c->prof && c->learn_warm;
+  if (graphed && !c->wgrad_graph) {
+    hipGraph_t graph = nullptr;
+    HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_wgrad(c);
+    hipError_t e = hipStreamEndCapture(c->st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+    HCHECK(hipGraphInstantiate(&c->wgrad_graph, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+  }
   HCHECK(hipEventRecord(c->ev0, c->st));
-  int rc = enqueue_wgrad(c);
-  if (rc) return rc;
+  if (graphed) HCHECK(hipGraphLaunch(c->wgrad_graph, c->st));
+  else if ((rc = enqueue_wgrad(c))) return rc;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {
@@ -935,11 +955,25 @@ int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* ou
   HCHECK(hipSetDevice(c->device));
   int rc = stage_adam_hyp(c, eta_w);
   if (rc) return rc;
+  const bool graphed = c->use_graph && !c->prof && c->learn_warm;
+  if (graphed && (!c->apply_graph || c->apply_graph_scale != scale_by)) {
+    if (c->apply_graph) { hipGraphExecDestroy(c->apply_graph); c->apply_graph = nullptr; }
+    hipGraph_t graph = nullptr;
+    HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_apply(c, scale_by);
+    hipError_t e = hipStreamEndCapture(c->st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+    HCHECK(hipGraphInstantiate(&c->apply_graph, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    c->apply_graph_scale = scale_by;
+  }
   HCHECK(hipEventRecord(c->ev0, c->st));
-  rc = enqueue_apply(c, scale_by);
-  if (rc) return rc;
+  if (graphed) HCHECK(hipGraphLaunch(c->apply_graph, c->st));
+  else if ((rc = enqueue_apply(c, scale_by))) return rc;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
+  c->learn_warm = true;
   if (out) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -1044,7 +1078,7 @@ int cora_bind_wgrad_buffer(cora_ctx* c, void* dev, size_t n) {
   if (!c) return -1;
   if (!dev || n != c->nW) FAIL(-1, "bind_wgrad_buffer: size mismatch");
   if (((uintptr_t)dev) % 16) FAIL(-1, "bind_wgrad_buffer: pointer must be 16-byte aligned");
-  if (c->learn_graph) { hipStreamSynchronize(c->st); hipGraphExecDestroy(c->learn_graph); c->learn_graph = nullptr; }
+  drop_learn_graphs(c);
   c->dW = (float*)dev;   // the old buffer stays in c->allocs and is freed with the ctx
   c->dW_owned = false;
   return 0;
