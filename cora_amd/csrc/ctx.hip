@@ -363,8 +363,9 @@ int errors_pass(cora_ctx* c, int slot) {
   return 0;
 }
 
-// one inference step t: errors, dE/dh for every un-frozen vode, layer scaling, clip, momentum SGD
-int infer_step(cora_ctx* c, int t) {
+// first half of inference step t: errors, energies, dE/dh for every un-frozen vode with layer
+// scaling, and the per-vode sums of squares of this shard (row t of c->sumsq)
+int infer_grad_step(cora_ctx* c, int t) {
   const int L = c->L;
   int rc = 0;
   double* ss = c->sumsq + (long long)t * (L + 2) * 8;
@@ -409,6 +410,14 @@ int infer_step(cora_ctx* c, int t) {
     if (rc) return rc;
   }
   }
+  return 0;
+}
+
+// second half: clip by the global norm (row t of c->sumsq -- summed over ranks first in the exact
+// data-parallel mode), momentum SGD on every vode
+int infer_update_step(cora_ctx* c, int t) {
+  const int L = c->L;
+  double* ss = c->sumsq + (long long)t * (L + 2) * 8;
   UpdateP u; memset(&u, 0, sizeof u);
   u.h = c->Hs; u.m = c->Ms; u.g = c->Gs; u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
   u.sumsq = ss; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
@@ -429,16 +438,25 @@ int infer_step(cora_ctx* c, int t) {
   return 0;
 }
 
-int enqueue_infer(cora_ctx* c, int T) {
+int infer_step(cora_ctx* c, int t) {
+  int rc = infer_grad_step(c, t);
+  return rc ? rc : infer_update_step(c, t);
+}
+
+void zero_infer_logs(cora_ctx* c, int T) {
   const int L = c->L;
-  // Zero-fill KERNELS, not hipMemsetAsync: memset nodes inside the captured graph were observed
-  // (ROCm 7.2, gfx950) to leave the 100 MB momentum buffer stale on some replays, which blew the
-  // vodes up at step 1 of a later batch; tests/test_gpu_parity.py::test_graph_replay_matches_eager
-  // guards this.
   launch_zero(c->energies, ((sizeof(double) * (size_t)T * (L + 3)) + 15) / 16 * 16, c->st);
   launch_zero(c->sumsq, sizeof(double) * (size_t)T * (L + 2) * 8, c->st);
   if (c->fused) launch_zero(c->esum, sizeof(double) * (size_t)T * (L + 3) * 8, c->st);
   launch_zero(c->Ms, sizeof(float) * (size_t)c->nV, c->st);   // optim_h.init, :414
+}
+
+int enqueue_infer(cora_ctx* c, int T) {
+  // Zero-fill KERNELS, not hipMemsetAsync: memset nodes inside the captured graph were observed
+  // (ROCm 7.2, gfx950) to leave the 100 MB momentum buffer stale on some replays, which blew the
+  // vodes up at step 1 of a later batch; tests/test_gpu_parity.py::test_graph_replay_matches_eager
+  // guards this.
+  zero_infer_logs(c, T);
   for (int t = 0; t < T; ++t) {
     int rc = infer_step(c, t);
     if (rc) return rc;
@@ -1065,6 +1083,58 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
     for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
     out->final_h_energy = eh; out->final_w_energy = ew;
     out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;
+  }
+  return 0;
+}
+
+// ---- exact data-parallel clip: the inference loop driven step by step from the host ---------------
+// (see include/cora_hip.h: cora_infer_begin / _grad / _sumsq / _update / _end)
+int cora_infer_begin(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h) {
+  if (!c) return -1;
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!eta_h) FAIL(-1, "eta_h is NULL");
+  HCHECK(hipSetDevice(c->device));
+  int rc = upload_x(c, x, x_on_device);
+  if (rc) return rc;
+  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  c->last_T = T;
+  zero_infer_logs(c, T);
+  return 0;
+}
+int cora_infer_grad(cora_ctx* c, int t) {
+  if (!c) return -1;
+  if (t < 0 || t >= c->last_T) FAIL(-1, "step index out of range");
+  HCHECK(hipSetDevice(c->device));
+  return infer_grad_step(c, t);
+}
+int cora_infer_sumsq(cora_ctx* c, int t, double* host, size_t n, int set) {
+  if (!c) return -1;
+  if (t < 0 || t >= c->last_T) FAIL(-1, "step index out of range");
+  if (!host || n != (size_t)(c->L + 2) * 8) FAIL(-1, "sumsq row has (L+2)*8 doubles");
+  HCHECK(hipSetDevice(c->device));
+  double* row = c->sumsq + (long long)t * (c->L + 2) * 8;
+  if (set) HCHECK(hipMemcpyAsync(row, host, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+  else HCHECK(hipMemcpyAsync(host, row, sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  return 0;
+}
+int cora_infer_update(cora_ctx* c, int t) {
+  if (!c) return -1;
+  if (t < 0 || t >= c->last_T) FAIL(-1, "step index out of range");
+  HCHECK(hipSetDevice(c->device));
+  return infer_update_step(c, t);
+}
+int cora_infer_end(cora_ctx* c, cora_step_out* out) {
+  if (!c) return -1;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->st));
+  if (out && c->last_T > 0) {
+    std::vector<double> en((size_t)c->L + 3);
+    if (energy_row(c, c->last_T - 1, en.data())) FAIL(-2, "energy read-back failed");
+    double tot = 0.0;
+    for (double v : en) tot += v;
+    out->final_h_energy = tot;
   }
   return 0;
 }

@@ -6,9 +6,12 @@ dE/dW by 1/B (:484).  Sharding the batch over k ranks therefore needs exactly on
 batch: the SUM over ranks of the flat dE/dW buffer, after which every rank applies the identical
 clip + AdamW update with scale_by = 1/(B_local * k).  Inference (T vode steps) needs no collective.
 
-Deviation, documented in DESIGN.md: optax.clip_by_global_norm on the vode gradients couples the
-whole batch every inference step; here the norm is taken per shard ('local' mode), which is
-identical whenever no shard clips.
+optax.clip_by_global_norm on the vode gradients couples the whole batch every inference step.
+Two modes: 'local' (default, fast: the whole T-step loop stays one captured graph and each shard
+clips by its own norm -- identical to the reference whenever no shard clips) and
+`exact_clip=True` (the per-vode sums of squares are all-reduced between the gradient half and the
+update half of every inference step -- the reference's trajectory for the global batch, at the
+price of one host round trip per step).
 """
 from __future__ import annotations
 
@@ -36,11 +39,12 @@ def shard_slice(batch: int, rank: int, world: int) -> slice:
 class DataParallel:
     """Owns the torch view of the flat dE/dW buffer and runs the one collective of the step."""
 
-    def __init__(self, model, batch_size: int, group=None):
+    def __init__(self, model, batch_size: int, group=None, exact_clip: bool = False):
         import torch
         import ctypes as C
         from . import _lib
         self.group = group
+        self.exact_clip = bool(exact_clip)
         ctx = model._ensure_ctx(batch_size)
         dev = torch.device("cuda", model.device)
         self.buf = torch.zeros(model._nW, dtype=torch.float32, device=dev)
@@ -51,6 +55,36 @@ class DataParallel:
     def allreduce(self) -> int:
         # cora_wgrad synchronised its stream before returning, so the buffer is complete here.
         import torch
-        world = allreduce_sum_(self.buf, self.group)
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend(self.group) == "gloo":
+            host = self.buf.cpu()            # gloo (CPU tests, several ranks on one GPU): stage through the host
+            world = allreduce_sum_(host, self.group)
+            self.buf.copy_(host)
+        else:
+            world = allreduce_sum_(self.buf, self.group)
         torch.cuda.synchronize(self.buf.device)
         return world
+
+    def infer_exact(self, model, ctx, x, T: int, eta_h, out) -> None:
+        """The T-step loop with the batch-global clip norm (cora_infer_begin/.../end)."""
+        import ctypes as C
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        lib = _lib.load()
+        fp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(lib.cora_infer_begin(ctx, fp(x), 0, T, fp(eta_h)), ctx)
+        row = np.zeros((model.L + 2) * 8, dtype=np.float64)
+        gpu_coll = dist.is_initialized() and dist.get_backend(self.group) != "gloo"
+        for t in range(T):
+            _lib.check(lib.cora_infer_grad(ctx, t), ctx)
+            _lib.check(lib.cora_infer_sumsq(ctx, t, fp(row), row.size, 0), ctx)
+            tt = torch.from_numpy(row)
+            if gpu_coll:
+                tt = tt.to(self.buf.device)
+            allreduce_sum_(tt, self.group)
+            row[:] = tt.cpu().numpy()
+            _lib.check(lib.cora_infer_sumsq(ctx, t, fp(row), row.size, 1), ctx)
+            _lib.check(lib.cora_infer_update(ctx, t), ctx)
+        _lib.check(lib.cora_infer_end(ctx, C.byref(out)), ctx)

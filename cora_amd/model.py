@@ -462,7 +462,10 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
     if model._dp is None:
         _lib.check(lib.cora_step(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w), C.byref(out)), ctx)
     else:
-        _lib.check(lib.cora_infer(ctx, _fptr(x), 0, T, _fptr(eta_h), C.byref(out)), ctx)
+        if model._dp.exact_clip:
+            model._dp.infer_exact(model, ctx, x, T, eta_h, out)
+        else:
+            _lib.check(lib.cora_infer(ctx, _fptr(x), 0, T, _fptr(eta_h), C.byref(out)), ctx)
         _lib.check(lib.cora_wgrad(ctx, C.byref(out)), ctx)
         world = model._dp.allreduce()
         _lib.check(lib.cora_apply_wgrad(ctx, C.c_float(eta_w), C.c_float(1.0 / (B * world)), C.byref(out)), ctx)

@@ -125,6 +125,22 @@ int cora_infer(cora_ctx* ctx, const float* x, int x_on_device, int T, const floa
                cora_step_out* out);
 int cora_wgrad(cora_ctx* ctx, cora_step_out* out);
 int cora_apply_wgrad(cora_ctx* ctx, float eta_w, float scale_by, cora_step_out* out);
+/* The inference loop of cora_infer driven step by step from the host, for the EXACT data-parallel
+ * vode-gradient clip: optax.clip_by_global_norm (/root/reference/examples/debug_transformer_wandb.py:1137-1140)
+ * takes the norm over the whole batch, so with the batch sharded over ranks the per-vode sums of
+ * squares of step t must be summed over ranks between the gradient half and the update half:
+ *   cora_infer_begin(x, T, eta_h);
+ *   for t < T: cora_infer_grad(t); cora_infer_sumsq(t, row, n, 0); <all-reduce SUM row>;
+ *              cora_infer_sumsq(t, row, n, 1); cora_infer_update(t);
+ *   cora_infer_end(out)         -- out->final_h_energy is this shard's part
+ * row = (L+2)*8 doubles (8 partial sums per vode).  Eager launches, one host round trip per step:
+ * the captured single-graph cora_infer with the per-shard norm stays the fast path. */
+int cora_infer_begin(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h);
+int cora_infer_grad(cora_ctx* ctx, int t);
+int cora_infer_sumsq(cora_ctx* ctx, int t, double* host_row, size_t n_doubles, int set);
+int cora_infer_update(cora_ctx* ctx, int t);
+int cora_infer_end(cora_ctx* ctx, cora_step_out* out);
+
 /* Device pointer + length of the flat dE/dW buffer (same layout as the weight arena). */
 int cora_wgrad_buffer(cora_ctx* ctx, void** dev_ptr, size_t* n_floats);
 /* Let the caller own the buffer instead (e.g. a torch tensor used for the all-reduce). */
