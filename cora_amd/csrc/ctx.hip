@@ -84,6 +84,7 @@ struct cora_ctx {
   float apply_graph_scale = 0.f;   // cora_step: weight gradients + AdamW + reconstruction, captured once
   float* hyp_dev = nullptr;               // {eta_w, 1 - b1^count, 1 - b2^count} for the captured AdamW
   double* host_out = nullptr;             // pinned: scalars read back at the end of cora_step
+  float* host_in = nullptr;               // pinned staging of eta_h[Tmax] + AdamW hyper-parameters (no sync to upload)
   hipEvent_t ev2 = nullptr;
   bool use_graph = true;
   bool warmed = false;
@@ -600,7 +601,8 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 3)); c->esum = (double*)tmp;
   DA(tmp, 8); c->scal = (double*)tmp;
   DA(c->hyp_dev, 4);
-  if (hipHostMalloc((void**)&c->host_out, sizeof(double) * ((size_t)(L + 3) * 9 + 8), hipHostMallocDefault) != hipSuccess)
+  if (hipHostMalloc((void**)&c->host_out, sizeof(double) * ((size_t)(L + 3) * 9 + 8), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->host_in, sizeof(float) * ((size_t)c->Tmax + 8), hipHostMallocDefault) != hipSuccess)
     return fail(-2);
 #undef DA
   // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
@@ -632,6 +634,7 @@ int cora_destroy(cora_ctx* c) {
   drop_learn_graphs(c);
   for (void* p : c->allocs) hipFree(p);
   if (c->host_out) hipHostFree(c->host_out);
+  if (c->host_in) hipHostFree(c->host_in);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->ev2) hipEventDestroy(c->ev2);
@@ -1043,10 +1046,19 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   if (!eta_h) FAIL(-1, "eta_h is NULL");
   HCHECK(hipSetDevice(c->device));
   const int L = c->L;
-  int rc = upload_x(c, x, x_on_device);
+  int rc = upload_x(c, x, x_on_device);   // host x: staged synchronously by the runtime; device x: valid until we return
   if (rc) return rc;
-  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
-  if ((rc = stage_adam_hyp(c, eta_w))) return rc;   // also synchronises: x / eta_h are caller-owned
+  // eta_h and the AdamW scalars go through pinned memory the ctx owns: asynchronous, and the call
+  // ends with a stream synchronisation before that memory is written again
+  c->adam_count += 1;
+  memcpy(c->host_in, eta_h, sizeof(float) * T);
+  float* hy = c->host_in + c->Tmax;
+  hy[0] = eta_w;
+  hy[1] = (float)(1.0 - pow((double)c->cfg.adam_b1, (double)c->adam_count));
+  hy[2] = (float)(1.0 - pow((double)c->cfg.adam_b2, (double)c->adam_count));
+  hy[3] = 0.f;
+  HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipMemcpyAsync(c->hyp_dev, hy, sizeof(float) * 4, hipMemcpyHostToDevice, c->st));
   c->last_T = T;
   hipGraphExec_t gi = nullptr;
   if ((rc = infer_graph(c, T, &gi))) return rc;
