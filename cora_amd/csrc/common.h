@@ -86,6 +86,10 @@ struct GemmP {
 };
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
+#define GEMM_MULTI_MAX 6
+struct GemmMulti { int n; int start[GEMM_MULTI_MAX + 1]; GemmP p[GEMM_MULTI_MAX]; };
+// n independent K-outer x K-outer (TN) problems in one launch; start[] is filled by the launcher
+void launch_gemm_multi_tn(const GemmMulti& m, hipStream_t st);
 
 // ---- attention ------------------------------------------------------------------------------------
 // qkv: [rows, 3D] (q | k | v, head h = columns h*dh..), O: [rows, D], lse2: [rows, H] (base-2 LSE)

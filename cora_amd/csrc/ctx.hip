@@ -508,14 +508,19 @@ int pick_splitk(long long tiles, int K) {
 }
 
 // C[g] (+)= -A^T B  with A [rows, R], B [rows, O]  (weight gradient, summed over the rows)
-void wgrad_gemm(cora_ctx* c, int G, const float* A, int R, long long sA, const float* Bm, int O, long long sB,
-                float* C, long long sC, int b_gelu) {
+GemmP wgrad_problem(cora_ctx* c, int G, const float* A, int R, long long sA, const float* Bm, int O, long long sB,
+                    float* C, long long sC, int b_gelu) {
   GemmP p = gemm_base(c, 2);
   p.groups = G;
   p.A = A; p.Bw = Bm; p.C = C;
   p.R = R; p.O = O; p.K = (int)c->BN; p.lda = R; p.ldb = O; p.ldc = O;
   p.sA = sA; p.sB = sB; p.sC = sC;
   p.alpha = -1.f; p.mode = OUT_ATOMIC; p.b_gelu = b_gelu;
+  return p;
+}
+void wgrad_gemm(cora_ctx* c, int G, const float* A, int R, long long sA, const float* Bm, int O, long long sB,
+                float* C, long long sC, int b_gelu) {
+  GemmP p = wgrad_problem(c, G, A, R, sA, Bm, O, sB, C, sC, b_gelu);
   long long tiles = (long long)((R + 127) / 128) * ((O + 63) / 64) * G;
   p.splitk = pick_splitk(tiles, p.K);
   run_gemm(c, p, true, true);
@@ -879,6 +884,32 @@ int enqueue_wgrad(cora_ctx* c) {
     if (rc) return rc;
   }
   // dE/dtheta = -(du/dtheta)^T e
+  if (c->fused) {
+    // the six contractions (K = B*N rows each, 56 output tiles in all) go out as ONE launch, split
+    // over K so that the launch has ~1k workgroups; launched one by one each filled a fraction of
+    // the chip (64..768 workgroups) and they took 256 us together
+    const float* r = err_ptr(c, 2);
+    const long long sD = (long long)R * D, sM = (long long)R * M, s3 = (long long)R * 3 * D;
+    GemmMulti m; memset(&m, 0, sizeof m);
+    m.n = 6;
+    m.p[0] = wgrad_problem(c, L, r, D, sD, c->a, M, sM, c->dW + c->oW2, (long long)D * M, 1);        // dW2 = -r^T gelu(a)
+    m.p[1] = wgrad_problem(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);   // dW1 = -da^T LN2(y)
+    m.p[2] = wgrad_problem(c, L, c->dqkv, 3 * D, s3, c->xn1, D, sD, c->dW + c->oWqkv, 3LL * D * D, 0);
+    m.p[3] = wgrad_problem(c, L, c->dy, D, sD, c->att, D, sD, c->dW + c->oWo, (long long)D * D, 0);   // dWo = -dy^T att
+    m.p[4] = wgrad_problem(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
+    m.p[5] = wgrad_problem(c, 1, err_ptr(c, L + 2), P, 0, vode_ptr(c, c->Hs, L + 1), D, 0, c->dW + c->oWout, 0, 0);
+    long long tiles = 0;
+    double fl = 0.0;
+    for (int k = 0; k < m.n; ++k) {
+      tiles += (long long)((m.p[k].R + 127) / 128) * ((m.p[k].O + 63) / 64) * m.p[k].groups;
+      fl += 2.0 * m.p[k].R * (double)m.p[k].O * m.p[k].K * m.p[k].groups;
+    }
+    const int sk = pick_splitk(tiles, (int)c->BN);
+    for (int k = 0; k < m.n; ++k) m.p[k].splitk = sk;
+    KScope s(c, K_GEMM_TN, fl, 0);
+    launch_gemm_multi_tn(m, c->st);
+    return 0;
+  }
   wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
   if (!c->fused) { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
   wgrad_gemm(c, 1, err_ptr(c, L + 2), P, 0, vode_ptr(c, c->Hs, L + 1), D, 0, c->dW + c->oWout, 0, 0);

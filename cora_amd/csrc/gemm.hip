@@ -41,7 +41,7 @@ __device__ __forceinline__ bf16x8 pack_bf16_lo(const float* lo, const float* hi4
 // Ah Bh + Ah Bl + Al Bh): products good to ~2^-16, for the forward predictions whose error
 // e = h - u cancels most leading bits of u
 template <int BK, bool AKO, bool BKO, int BF16>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const int by, const int bz) {
   constexpr int LDA_S = AKO ? (BM + 4) : (BK + 4);
   constexpr int LDB_S = BKO ? (BN + 4) : (BK + 4);
   constexpr int A_ELEMS = AKO ? BK * (BM + 4) : BM * (BK + 4);
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hi = lane >> 5;
-  const int g = blockIdx.z / p.splitk, sk = blockIdx.z % p.splitk;
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  const int g = bz / p.splitk, sk = bz % p.splitk;
+  const int row0 = bx * BM, col0 = by * BN;
 
   const float* A = p.A + (long long)g * p.sA;
   const float* Bw = p.Bw + (long long)g * p.sB;
@@ -254,10 +254,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   if (p.red) {
     double tot = block_sum_256(red, red_sh);
     if (tid == 0) {
-      if (p.mode == OUT_GRAD) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + (blockIdx.x & 7)], tot);
+      if (p.mode == OUT_GRAD) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + (bx & 7)], tot);
       else atomicAdd(&p.red[(long long)g * p.red_stride], tot);
     }
   }
+}
+
+template <int BK, bool AKO, bool BKO, int BF16>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  gemm_body<BK, AKO, BKO, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent TN problems (the weight-gradient contractions of one batch: different shapes,
+// each too small to fill the chip) in ONE launch: block -> (problem, tile) through a prefix table.
+template <int BF16>
+__global__ __launch_bounds__(256) void gemm_multi_tn_kernel(GemmMulti m) {
+  int q = 0;
+#pragma unroll
+  for (int k = 1; k < GEMM_MULTI_MAX; ++k) if (k < m.n && (int)blockIdx.x >= m.start[k]) q = k;
+  const GemmP& p = m.p[q];
+  int rel = (int)blockIdx.x - m.start[q];
+  const int tx = (p.R + BM - 1) / BM, ty = (p.O + BN - 1) / BN;
+  const int bx = rel % tx; rel /= tx;
+  const int by = rel % ty; rel /= ty;
+  gemm_body<16, true, true, BF16>(p, bx, by, rel);
 }
 
 template <int BK, int BF16>
@@ -281,4 +301,17 @@ void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
     if (bk32) launch_bk<32, 0>(p, a_kouter, b_kouter, grid, st);
     else launch_bk<16, 0>(p, a_kouter, b_kouter, grid, st);
   }
+}
+
+void launch_gemm_multi_tn(const GemmMulti& m_in, hipStream_t st) {
+  GemmMulti m = m_in;
+  int total = 0;
+  for (int k = 0; k < m.n; ++k) {
+    m.start[k] = total;
+    const GemmP& p = m.p[k];
+    total += ((p.R + BM - 1) / BM) * ((p.O + BN - 1) / BN) * p.groups * p.splitk;
+  }
+  m.start[m.n] = total;
+  if (m.p[0].bf16) hipLaunchKernelGGL((gemm_multi_tn_kernel<1>), dim3(total), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL((gemm_multi_tn_kernel<0>), dim3(total), dim3(256), 0, st, m);
 }
