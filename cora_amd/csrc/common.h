@@ -185,3 +185,5 @@ int launch_chain(const FusedP& p, int store_h, hipStream_t st);
 void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
 size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);
+struct TransposeSet { int n; const float* src[6]; float* dst[6]; int rows[6], cols[6], groups[6], zstart[6]; };
+void launch_transpose_set(const TransposeSet& t, hipStream_t st);   // all matrices of the set in one launch

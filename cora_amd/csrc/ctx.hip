@@ -302,12 +302,13 @@ void refresh_wt(cora_ctx* c) {
   if (!c->fused) return;
   const int D = c->D, M = c->M, L = c->L;
   KScope s(c, K_OTHER, 0, 8.0 * c->nWT);
-  launch_transpose(c->W + c->oWqkv, c->WT + c->tWqkv, 3 * D, D, L, c->st);
-  launch_transpose(c->W + c->oWo, c->WT + c->tWo, D, D, L, c->st);
-  launch_transpose(c->W + c->oW1, c->WT + c->tW1, M, D, L, c->st);
-  launch_transpose(c->W + c->oW2, c->WT + c->tW2, D, M, L, c->st);
-  launch_transpose(c->W + c->oWp, c->WT + c->tWp, D, c->P, 1, c->st);
-  launch_transpose(c->W + c->oWout, c->WT + c->tWout, c->P, D, 1, c->st);
+  TransposeSet t; memset(&t, 0, sizeof t);
+  auto add = [&](size_t so, size_t to, int rows, int cols, int groups) {
+    t.src[t.n] = c->W + so; t.dst[t.n] = c->WT + to; t.rows[t.n] = rows; t.cols[t.n] = cols; t.groups[t.n] = groups; ++t.n;
+  };
+  add(c->oWqkv, c->tWqkv, 3 * D, D, L); add(c->oWo, c->tWo, D, D, L); add(c->oW1, c->tW1, M, D, L);
+  add(c->oW2, c->tW2, D, M, L); add(c->oWp, c->tWp, D, c->P, 1); add(c->oWout, c->tWout, c->P, D, 1);
+  launch_transpose_set(t, c->st);
 }
 
 // flops of one block forward + VJP per image (2 FLOP per MAC): 48 N D^2 + 12 N^2 D

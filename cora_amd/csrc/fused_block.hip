@@ -744,12 +744,18 @@ int launch_chain(const FusedP& p, int store_h, hipStream_t st) {
   return 0;
 }
 
-// ---- transposed weight copies: dst[c][r] = src[r][c] per group -----------------------------------
-__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+// ---- transposed weight copies: dst[c][r] = src[r][c] per group; up to 6 matrices per launch -----------
+__global__ void transpose_kernel(TransposeSet t) {
   __shared__ float tile[32][33];
-  const float* s = src + (long long)blockIdx.z * rows * cols;
-  float* d = dst + (long long)blockIdx.z * rows * cols;
-  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  int z = blockIdx.z, q = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) if (k < t.n && z >= t.zstart[k]) q = k;
+  z -= t.zstart[q];
+  const int rows = t.rows[q], cols = t.cols[q];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (c0 >= cols || r0 >= rows) return;      // the grid is sized for the largest matrix of the set
+  const float* s = t.src[q] + (long long)z * rows * cols;
+  float* d = t.dst[q] + (long long)z * rows * cols;
   for (int k = threadIdx.y; k < 32; k += 8) {
     int rr = r0 + k, cc = c0 + threadIdx.x;
     tile[k][threadIdx.x] = (rr < rows && cc < cols) ? s[(long long)rr * cols + cc] : 0.f;
@@ -760,9 +766,19 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     if (rr < rows && cc < cols) d[(long long)cc * rows + rr] = tile[threadIdx.x][k];
   }
 }
+void launch_transpose_set(const TransposeSet& t_in, hipStream_t st) {
+  TransposeSet t = t_in;
+  int z = 0, mx = 1, my = 1;
+  for (int k = 0; k < t.n; ++k) {
+    t.zstart[k] = z; z += t.groups[k];
+    mx = max(mx, (t.cols[k] + 31) / 32); my = max(my, (t.rows[k] + 31) / 32);
+  }
+  hipLaunchKernelGGL(transpose_kernel, dim3(mx, my, z), dim3(32, 8), 0, st, t);
+}
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st) {
-  dim3 grid((cols + 31) / 32, (rows + 31) / 32, groups);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, src, dst, rows, cols);
+  TransposeSet t = {};
+  t.n = 1; t.src[0] = src; t.dst[0] = dst; t.rows[0] = rows; t.cols[0] = cols; t.groups[0] = groups;
+  launch_transpose_set(t, st);
 }
 
 // ---- dW[bias / LayerNorm parameters] -= sum over the 4 B wave slices of colpart (dW zeroed before) ------------

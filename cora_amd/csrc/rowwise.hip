@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ a,
 }
 void launch_sumsq(const float* a, long long n, float scale, double* out, hipStream_t st) {
   long long blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;   // one f64 atomic per block on ONE address: keep the fan-in small
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, n, scale, out);
 }
 
