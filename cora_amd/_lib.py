@@ -52,6 +52,8 @@ SIGNATURES = {
     "cora_set_optim": (C.c_int, [_P] + [C.c_float] * 7),
     "cora_step": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_float, C.POINTER(CoraStepOut)]),
     "cora_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(CoraStepOut)]),
+    "cora_set_grad_options": (C.c_int, [_P, C.c_int, C.c_float, C.c_int, C.c_float]),
+    "cora_step_ipc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.POINTER(CoraStepOut)]),
     "cora_infer_begin": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "cora_infer_grad": (C.c_int, [_P, C.c_int]),
     "cora_infer_sumsq": (C.c_int, [_P, C.c_int, _P, _SZ, C.c_int]),

@@ -147,6 +147,21 @@ void drop_learn_graphs(cora_ctx* c) {
   if (c->apply_graph) { hipGraphExecDestroy(c->apply_graph); c->apply_graph = nullptr; }
 }
 
+// layer scales g_l *= base^{(L+1) - l} (src/decoder_transformer.py:321-341; the un-frozen sensory vode has
+// index L+2) from the current cfg.use_scaling / scale_base; the captured inference graphs bake them
+int apply_grad_options(cora_ctx* c) {
+  float gs[64];
+  for (int l = 0; l <= c->L + 1; ++l)
+    c->scale_l[l] = c->cfg.use_scaling ? (float)pow((double)c->cfg.scale_base, (double)(c->L + 1 - l)) : 1.f;
+  c->sens_scale = c->cfg.use_scaling ? (float)pow((double)c->cfg.scale_base, -1.0) : 1.f;
+  for (int g = 0; g < 64; ++g) gs[g] = (g <= c->L) ? c->scale_l[g + 1] : 1.f;
+  if (hipMemcpyAsync(c->gscale, gs, sizeof gs, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+      hipStreamSynchronize(c->st) != hipSuccess) return -2;
+  for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+  c->graphs.clear();
+  return 0;
+}
+
 GemmP gemm_base(cora_ctx* c, int kind = 0 /* 0 forward, 1 backward-data, 2 weight-gradient */) {
   GemmP p;
   memset(&p, 0, sizeof p);
@@ -606,22 +621,12 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 2)); c->sumsq = (double*)tmp;
   DA(tmp, 16LL * (c->Tmax + 2) * (L + 3)); c->esum = (double*)tmp;
   DA(tmp, 8); c->scal = (double*)tmp;
-  DA(c->hyp_dev, 4);
+  DA(c->hyp_dev, 4 + 4LL * c->Tmax);   // [0..3] single step; then one {eta_w, bc1, bc2, -} per inference step (iPC mode)
   if (hipHostMalloc((void**)&c->host_out, sizeof(double) * ((size_t)(L + 3) * 9 + 8), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->host_in, sizeof(float) * ((size_t)c->Tmax + 8), hipHostMallocDefault) != hipSuccess)
     return fail(-2);
 #undef DA
-  // layer scales: g_l *= base^{(L+1) - l}  (src/decoder_transformer.py:321-341)
-  float gs[64];
-  for (int l = 0; l <= c->L + 1; ++l) {
-    float s = 1.f;
-    if (cfg->use_scaling) s = (float)pow((double)cfg->scale_base, (double)(c->L + 1 - l));
-    c->scale_l[l] = s;
-  }
-  c->sens_scale = cfg->use_scaling ? (float)pow((double)cfg->scale_base, -1.0) : 1.f;   // vode index L+2
-  for (int g = 0; g < 64; ++g) gs[g] = (g <= c->L) ? c->scale_l[g + 1] : 1.f;
-  if (hipMemcpyAsync(c->gscale, gs, sizeof gs, hipMemcpyHostToDevice, c->st) != hipSuccess ||
-      hipStreamSynchronize(c->st) != hipSuccess) { c->err = "initial upload failed"; return fail(-2); }
+  if (apply_grad_options(c)) { c->err = "initial upload failed"; return fail(-2); }
   // Launch every kernel of the inference step once outside stream capture (code-object load,
   // dynamic-LDS attributes).  All state is zero and eta = 0, so nothing observable changes.
   rc = enqueue_infer(c, 1);
@@ -825,6 +830,18 @@ int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, floa
   return 0;
 }
 
+int cora_set_grad_options(cora_ctx* c, int use_scaling, float scale_base, int use_grad_norm, float grad_norm_target) {
+  if (!c) return -1;
+  cora_config& f = c->cfg;
+  if (f.use_scaling == use_scaling && f.scale_base == scale_base && f.use_grad_norm == use_grad_norm &&
+      f.grad_norm_target == grad_norm_target) return 0;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->st));
+  f.use_scaling = use_scaling; f.scale_base = scale_base; f.use_grad_norm = use_grad_norm; f.grad_norm_target = grad_norm_target;
+  if (apply_grad_options(c)) FAIL(-2, "layer-scale upload failed");
+  return 0;
+}
+
 int infer_graph(cora_ctx* c, int T, hipGraphExec_t* out);
 
 int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, cora_step_out* out) {
@@ -943,20 +960,27 @@ int enqueue_wgrad(cora_ctx* c) {
 // clip + AdamW on dW (scaled by scale_by), transposes for the fused kernel, reconstruction with the
 // updated weights and its clipped MSE (:484-494).  eta_w and the bias corrections come from
 // c->hyp_dev so the sequence can sit in a captured graph.  No synchronisation.
-int enqueue_apply(cora_ctx* c, float scale_by) {
+int enqueue_adamw(cora_ctx* c, float scale_by, const float* hyp) {
   launch_zero(c->scal, 32, c->st);
   { KScope s(c, K_OTHER, 0, 4.0 * c->nW); launch_sumsq(c->dW, (long long)c->nW, scale_by, c->scal, c->st); }
   AdamP a; memset(&a, 0, sizeof a);
   a.w = c->W; a.g = c->dW; a.mu = c->amu; a.nu = c->anu; a.n = (long long)c->nW; a.sumsq = c->scal;
   a.gscale = scale_by; a.clip = c->cfg.clip_w; a.b1 = c->cfg.adam_b1; a.b2 = c->cfg.adam_b2;
-  a.eps = c->cfg.adam_eps; a.wd = c->cfg.adam_wd; a.hyp = c->hyp_dev;
+  a.eps = c->cfg.adam_eps; a.wd = c->cfg.adam_wd; a.hyp = hyp;
   { KScope s(c, K_OTHER, 0, 28.0 * c->nW); launch_adamw(a, c->st); }
   refresh_wt(c);
-  // reconstruction under status "forward" with the updated weights, :488-494
+  return 0;
+}
+// reconstruction under status "forward" with the current weights and its clipped MSE, :488-494
+int enqueue_recon(cora_ctx* c) {
   int rc = chain_forward(c, false, c->scal + 1);
   if (rc) return rc;
   if (!c->fused) { KScope s(c, K_OTHER, 0, 8.0 * c->n0); launch_mse(c->z, c->xp, c->n0, c->scal + 1, c->st); }
   return 0;
+}
+int enqueue_apply(cora_ctx* c, float scale_by) {
+  int rc = enqueue_adamw(c, scale_by, c->hyp_dev);
+  return rc ? rc : enqueue_recon(c);
 }
 
 // host side of one AdamW step: advance the count and stage {eta_w, 1 - b1^count, 1 - b2^count}
@@ -1179,6 +1203,62 @@ int cora_infer_end(cora_ctx* c, cora_step_out* out) {
     double tot = 0.0;
     for (double v : en) tot += v;
     out->final_h_energy = tot;
+  }
+  return 0;
+}
+
+// MODE 1 of train_on_batch (update_weights_every_inference_step, :418-439): every iteration is one
+// vode step followed by one weight step at the updated vodes; see include/cora_hip.h
+int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, const float* eta_w, cora_step_out* out) {
+  if (!c) return -1;
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!eta_h || !eta_w) FAIL(-1, "eta_h / eta_w is NULL");
+  HCHECK(hipSetDevice(c->device));
+  const int L = c->L;
+  int rc = upload_x(c, x, x_on_device);
+  if (rc) return rc;
+  std::vector<float> hy((size_t)4 * T);
+  for (int t = 0; t < T; ++t) {
+    const double cnt = (double)(c->adam_count + t + 1);
+    hy[4 * t] = eta_w[t];
+    hy[4 * t + 1] = (float)(1.0 - pow((double)c->cfg.adam_b1, cnt));
+    hy[4 * t + 2] = (float)(1.0 - pow((double)c->cfg.adam_b2, cnt));
+    hy[4 * t + 3] = 0.f;
+  }
+  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipMemcpyAsync(c->hyp_dev + 4, hy.data(), sizeof(float) * hy.size(), hipMemcpyHostToDevice, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  c->adam_count += T;
+  c->last_T = T;
+  HCHECK(hipEventRecord(c->ev0, c->st));
+  zero_infer_logs(c, T);
+  for (int t = 0; t < T && !rc; ++t) {
+    rc = infer_step(c, t);                                                     // :421-424
+    if (!rc) rc = enqueue_wgrad(c);                                            // :426-427
+    if (!rc) rc = enqueue_adamw(c, 1.0f / (float)c->B, c->hyp_dev + 4 + 4 * t);  // :428
+  }
+  if (rc) return rc;
+  HCHECK(hipEventRecord(c->ev1, c->st));
+  if ((rc = enqueue_recon(c))) return rc;
+  HCHECK(hipEventRecord(c->ev2, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  c->learn_warm = true;
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
+    hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
+    std::vector<double> en((size_t)L + 3);
+    if (energy_row(c, T - 1, en.data())) FAIL(-2, "energy read-back failed");
+    double tot = 0.0;
+    for (double v : en) tot += v;
+    out->final_h_energy = tot;
+    HCHECK(hipMemcpy(en.data(), c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * en.size(), hipMemcpyDeviceToHost));
+    tot = 0.0;
+    for (double v : en) tot += v;
+    out->final_w_energy = tot;
+    double sse = 0.0;
+    HCHECK(hipMemcpy(&sse, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost));
+    out->train_mse = sse / (double)c->n0;
   }
   return 0;
 }

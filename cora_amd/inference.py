@@ -54,6 +54,7 @@ def _run_unmask(model: TransformerDecoder, optim_h: Optim, x_true, x_init, mask,
     if T > model.max_T:
         raise ValueError(f"T={T} exceeds the model's max_T={model.max_T}")
     rh = optim_h._recipe()
+    model._grad_options(True)
     model._apply_recipes_h(optim_h)
     optim_h.clear()
     optim_h.init()                                                            # :840-841

@@ -139,9 +139,6 @@ class TransformerDecoder:
     def __init__(self, config: TransformerConfig, *, seed: int = 42, device: int = 0, max_T: int = 64,
                  compute_dtype: str = "fp32"):
         _lib.load()                      # fail loudly if the HIP library is missing
-        if config.update_weights_every_inference_step:
-            raise NotImplementedError("iPC mode (update_weights_every_inference_step=True) is outside "
-                                      "the implemented hot path (SURVEY 8(f) rank 4)")
         if config.use_vode_state_layernorm:
             raise NotImplementedError("use_vode_state_layernorm is outside the implemented hot path")
         if compute_dtype not in ("fp32", "bf16"):
@@ -348,6 +345,15 @@ class TransformerDecoder:
             self._optim_sig = sig
         return rh, rw
 
+    def _grad_options(self, conditioned: bool):
+        """Layer scaling / per-leaf normalisation as configured (MODE 2, inference-only loops), or off
+        (MODE 1 of train_on_batch applies the raw gradients, reference :421-424)."""
+        c = self.config
+        _lib.check(_lib.load().cora_set_grad_options(
+            self._ctx, int(bool(c.use_inference_lr_scaling) and conditioned),
+            C.c_float(float(c.inference_lr_scale_base if c.inference_lr_scale_base is not None else 1.0)),
+            int(bool(c.use_vode_grad_norm) and conditioned), C.c_float(float(c.vode_grad_norm_target))), self._ctx)
+
     def _apply_recipes_h(self, optim_h: Optim):
         """Vode-optimizer half only (inference-only loops); the weight half keeps its last values."""
         rh = optim_h._recipe()
@@ -459,7 +465,14 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
     eta_w = lr_at(rw.base.learning_rate, optim_w.count)
     out = _lib.CoraStepOut()
     model._x_host = x.copy()
-    if model._dp is None:
+    model._grad_options(not model.config.update_weights_every_inference_step)
+    if model.config.update_weights_every_inference_step:      # MODE 1 (iPC), reference :418-439
+        if model._dp is not None:
+            raise NotImplementedError("iPC mode is single-GPU (one all-reduce per inference step is not built)")
+        eta_ws = np.array([lr_at(rw.base.learning_rate, optim_w.count + t) for t in range(T)], dtype=np.float32)
+        _lib.check(lib.cora_step_ipc(ctx, _fptr(x), 0, T, _fptr(eta_h), _fptr(eta_ws), C.byref(out)), ctx)
+        optim_w.count += T - 1                               # the common `count += 1` below makes it T
+    elif model._dp is None:
         _lib.check(lib.cora_step(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w), C.byref(out)), ctx)
     else:
         if model._dp.exact_clip:

@@ -125,6 +125,22 @@ int cora_infer(cora_ctx* ctx, const float* x, int x_on_device, int T, const floa
                cora_step_out* out);
 int cora_wgrad(cora_ctx* ctx, cora_step_out* out);
 int cora_apply_wgrad(cora_ctx* ctx, float eta_w, float scale_by, cora_step_out* out);
+/* Gradient conditioning of the vode step, changeable after cora_create: exponential layer scaling
+ * (:308-350) and per-leaf normalisation (:353-389).  The reference applies them in MODE 2 of
+ * train_on_batch and in the inference-only loops, but not in MODE 1 (:421-424), so a host that mixes
+ * the two switches here.  Drops the captured inference graphs when something changes. */
+int cora_set_grad_options(cora_ctx* ctx, int use_scaling, float scale_base, int use_grad_norm, float grad_norm_target);
+
+/* MODE 1 of train_on_batch, `update_weights_every_inference_step` (iPC,
+ * /root/reference/src/decoder_transformer.py:418-439): T iterations of { one vode step on the RAW
+ * gradients -- the reference applies neither layer scaling nor gradient normalisation in this mode,
+ * so call cora_set_grad_options(ctx, 0, .., 0, ..) first --, dE/dW at the updated vodes,
+ * clip + AdamW with scale 1/B }, then the "forward" reconstruction.  eta_h[T], eta_w[T] = the two
+ * schedules (the AdamW count advances by T).  out: energies / MSE as in cora_step, the gradients of the
+ * LAST iteration stay readable (cora_get_vode_grad / cora_get_wgrad).  Eager launches. */
+int cora_step_ipc(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h,
+                  const float* eta_w, cora_step_out* out);
+
 /* The inference loop of cora_infer driven step by step from the host, for the EXACT data-parallel
  * vode-gradient clip: optax.clip_by_global_norm (/root/reference/examples/debug_transformer_wandb.py:1137-1140)
  * takes the norm over the whole batch, so with the batch sharded over ranks the per-vode sums of

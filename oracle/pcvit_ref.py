@@ -448,3 +448,53 @@ def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Option
         loss = ((xhat.clamp(0.0, 1.0).reshape(-1) - xt.reshape(-1)) ** 2).mean()
     return {"recons": recons, "xhat": xhat.numpy(), "loss": float(loss), "energies": np.array(energies),
             "grad_norms": np.array(norms), "h": [t.numpy() for t in hs], "sensory": hsens.numpy()}
+
+
+def train_on_batch_ipc(T: int, x: np.ndarray, weights: Dict[str, np.ndarray], h: List[np.ndarray], pos: np.ndarray,
+                       dims: Dims, hp: Hyper, eta_h: Sequence[float], eta_w: Sequence[float],
+                       adam: Optional[AdamState] = None, dtype=torch.float64):
+    """src/decoder_transformer.py:392-499, MODE 1 (`update_weights_every_inference_step`, :418-439):
+    every iteration is one vode step on the RAW gradients (no layer scaling, no normalisation: the
+    scan body at :421-424 hands h_grad straight to optim_h) followed by dE/dW at the updated vodes
+    and one clip + AdamW weight step with scale 1/B (:426-428).  Returns what the parity test compares."""
+    W = {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+    hs = [torch.as_tensor(np.asarray(t), dtype=dtype) for t in h]
+    pos_t = torch.as_tensor(np.asarray(pos), dtype=dtype)
+    y = torch.as_tensor(np.asarray(x), dtype=dtype)
+    B = y.shape[0]
+    adam = adam if adam is not None else AdamState()
+    mom = [torch.zeros_like(t) for t in hs]
+    keys = list(W.keys())
+    energies, w_energies = [], []
+    grads = w_grad = None
+    for t in range(T):
+        E, _, grads, _ = h_gradients(hs, W, pos_t, y, dims, hp)
+        energies.append(float(E))
+        g_clip = _clip(list(grads), hp.clip_h)
+        mom = [g + hp.momentum * m for g, m in zip(g_clip, mom)]
+        hs = [hh - eta_h[t] * m for hh, m in zip(hs, mom)]
+        Wg = {k: v.detach().clone().requires_grad_(True) for k, v in W.items()}
+        us = predictions(hs, Wg, pos_t, dims)
+        Ew = sum(layer_energies(hs, us, y, hp.l1, hp.l2))
+        w_energies.append(float(Ew.detach()))
+        wg = torch.autograd.grad(Ew, [Wg[k] for k in keys])
+        w_grad = {k: g.detach() for k, g in zip(keys, wg)}
+        g_list = _clip([w_grad[k] * (1.0 / B) for k in keys], hp.clip_w)
+        adam.count += 1
+        newW = {}
+        for k, g in zip(keys, g_list):
+            mu = torch.as_tensor(adam.mu.get(k, np.zeros(g.shape)), dtype=dtype)
+            nu = torch.as_tensor(adam.nu.get(k, np.zeros(g.shape)), dtype=dtype)
+            mu = hp.b1 * mu + (1 - hp.b1) * g
+            nu = hp.b2 * nu + (1 - hp.b2) * g * g
+            upd = (mu / (1 - hp.b1 ** adam.count)) / (torch.sqrt(nu / (1 - hp.b2 ** adam.count)) + hp.eps) + hp.wd * W[k]
+            newW[k] = W[k] - eta_w[t] * upd
+            adam.mu[k], adam.nu[k] = mu.numpy(), nu.numpy()
+        W = newW
+    with torch.no_grad():
+        xhat = predictions(hs, W, pos_t, dims, chain=True)[-1]
+        mse = ((xhat.clamp(0.0, 1.0) - y.clamp(0.0, 1.0)) ** 2).mean()
+    return {"energies": np.array(energies), "w_energies": np.array(w_energies),
+            "final_h_grad": [g.detach().numpy() for g in grads], "w_grad": {k: v.numpy() for k, v in w_grad.items()},
+            "h": [t.detach().numpy() for t in hs], "weights": {k: v.detach().numpy() for k, v in W.items()},
+            "train_mse": float(mse), "adam": adam}

@@ -136,6 +136,53 @@ def test_vode_grad_norm_option(name):
     run_case(name, use_grad_norm=True, grad_norm_target=1.5, clip_h=2.0)
 
 
+@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4"])
+def test_ipc_mode_weight_update_every_step(name):
+    """MODE 1 of train_on_batch (`update_weights_every_inference_step`, reference :418-439) against the
+    oracle: vodes and energies to the fp32 bar.  AdamW's first steps turn every gradient entry into
+    roughly +-eta_w regardless of its size, so weights after T such steps are compared on the
+    entries whose fp64 gradient is not noise-sized (|g| > 1e-3 max|g|), and the LAST iteration's vode
+    gradient -- evaluated with weights that went through T-1 such steps -- is held to 1e-3."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = CASES[name]
+    case = make_case(shape, p, D, H, L, B, seed=77, clip_h=3.0)
+    model, optim_w, optim_h = build_model(case, ipc=True)
+    eta, eta_w = [0.095] * T, [1e-3] * T
+    args = (T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], eta, eta_w)
+    ref = R.train_on_batch_ipc(*args)
+    r32 = R.train_on_batch_ipc(*args, dtype=torch.float32)
+    Eh, Ew, gh, gw, mse = ca.train_on_batch(T, case["x"], model=model, optim_w=optim_w, optim_h=optim_h)
+    assert optim_w.count == T
+    tot, _ = ca.step_energies(model, T)
+    errs, floor = {}, {}
+
+    def put(key, got, want, f32):
+        want = np.asarray(want, dtype=np.float64)
+        sc = np.abs(want).max() + 1e-30
+        errs[key] = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / sc)
+        floor[key] = float(np.abs(np.asarray(f32, dtype=np.float64) - want).max() / sc)
+
+    put("energies", tot, ref["energies"], r32["energies"])
+    put("final_w_energy", Ew, ref["w_energies"][-1], r32["w_energies"][-1])
+    put("train_mse", mse, ref["train_mse"], r32["train_mse"])
+    for l in range(L + 2):
+        put(f"h{l}", model.vodes[l].h.get(), ref["h"][l], r32["h"][l])
+        put(f"gh{l}", gh[l], ref["final_h_grad"][l], r32["final_h_grad"][l])
+    neww = model.get_weights()
+    gmax = max(np.abs(v).max() for v in ref["w_grad"].values())
+    for k, v in ref["weights"].items():
+        sel = np.abs(ref["w_grad"][k]) > 1e-3 * gmax
+        if sel.any():
+            d = np.abs(neww[k].astype(np.float64) - v)[sel].max()
+            d32 = np.abs(r32["weights"][k].astype(np.float64) - v)[sel].max()
+            errs["w" + k] = float(d / (T * 1e-3)); floor["w" + k] = float(d32 / (T * 1e-3))   # in units of the total step size
+    model.close()
+    bad = {k: (v, floor[k]) for k, v in errs.items()
+           if not v <= (max(2e-2, 3.0 * floor[k]) if k.startswith("w.") else
+                        max(1e-3 if k.startswith("gh") else TOL, 3.0 * floor[k]))}
+    assert not bad, f"{name}: iPC parity failures (err, fp32 floor): {bad}"
+
+
 def test_two_batches_persistent_state_and_adam():
     """vodes persist across batches, AdamW moments and count persist (reference _optim.py:47,128)."""
     import cora_amd as ca

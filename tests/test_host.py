@@ -136,8 +136,6 @@ def test_create_fails_loudly_without_gpu_or_on_bad_config():
 
 def test_unsupported_modes_raise():
     with pytest.raises(NotImplementedError):
-        ca.TransformerDecoder(ca.create_config(update_weights_every_inference_step=True))
-    with pytest.raises(NotImplementedError):
         ca.TransformerDecoder(ca.create_config(use_vode_state_layernorm=True))
 
 

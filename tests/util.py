@@ -26,13 +26,13 @@ def make_case(image_shape, patch, D, H, L, B, seed=0, l1=0.0, l2=0.0, clip_h=200
     return dict(dims=dims, W=W, pos=pos, x=x, h=h, hp=hp, h0=h0)
 
 
-def build_model(case, max_T=64, compute_dtype="fp32"):
+def build_model(case, max_T=64, compute_dtype="fp32", ipc=False):
     import cora_amd as ca
     d, hp = case["dims"], case["hp"]
     cfg = ca.TransformerConfig(
         image_shape=d.image_shape, hidden_size=d.D, num_heads=d.H, num_blocks=d.L,
         patch_size=d.patch_size, use_noise=True, use_inference_lr_scaling=hp.use_scaling,
-        inference_lr_scale_base=hp.scale_base, update_weights_every_inference_step=False,
+        inference_lr_scale_base=hp.scale_base, update_weights_every_inference_step=ipc,
         use_status_init_in_training=False, use_status_init_in_unmasking=False,
         intermediate_l1_coeff=hp.l1, intermediate_l2_coeff=hp.l2,
         use_vode_grad_norm=hp.use_grad_norm, vode_grad_norm_target=hp.grad_norm_target)
