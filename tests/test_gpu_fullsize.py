@@ -1,0 +1,89 @@
+"""Full-size checks at BASELINE.json's measured configuration (cfg 2: N=64, P=48, D=64, H=1, L=6,
+B=200, T=20), where the fp64 oracle is too slow to be the checker.  Size-independent properties:
+
+* two independent kernel implementations of the same math -- the fused per-(block, image) kernel
+  and the per-op path (GEMM / attention / LayerNorm kernels, CORA_NO_FUSED=1) -- must land on the
+  same vodes, energies, weight gradients and updated weights after a whole step;
+* the energy logged by step 0 of the inference loop equals `energy(model=...)` evaluated by the
+  per-op kernels at the same vodes;
+* images are independent given the weights (the energy is a plain sum over the batch,
+  /root/reference/src/decoder_transformer.py:305) when the batch-global clip does not fire: the two
+  halves of the batch run as their own B=100 problems give the same vodes as the B=200 run."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, clip_h, seed=5):
+    import cora_amd as ca
+    mc = ca.MODEL_CONFIGS["6block"]
+    tc = ca.transformer_config_from(mc)
+    tc.use_status_init_in_training = False
+    tc.update_weights_every_inference_step = False
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (B,) + tuple(tc.image_shape)).astype(np.float32)
+    h0 = (0.01 * rng.standard_normal((B, 64, 48))).astype(np.float32)
+    return ca, mc, tc, x, h0
+
+
+def _run(ca, mc, tc, x, h0, T, clip_h, sl=slice(None), fused=True):
+    if fused:
+        os.environ.pop("CORA_NO_FUSED", None)
+    else:
+        os.environ["CORA_NO_FUSED"] = "1"
+    try:
+        model = ca.TransformerDecoder(tc, seed=42, max_T=max(T, 32))
+        xs, hs = x[sl], h0[sl]
+        model.init_vodes(xs.shape[0], h0=hs)
+    finally:
+        os.environ.pop("CORA_NO_FUSED", None)
+    h_steps = ([ca.clip_by_global_norm(clip_h)] if clip_h else []) + [ca.sgd(mc.peak_lr_hidden, momentum=mc.hidden_momentum)]
+    optim_h = ca.Optim(lambda: ca.chain(*h_steps))
+    optim_w = ca.Optim(lambda: ca.chain(ca.clip_by_global_norm(mc.w_grad_clip_norm), ca.adamw(1e-3, weight_decay=mc.weight_decay)), model)
+    with ca.step(model):
+        ca.forward(xs, model=model)
+    e0, _ = ca.energy(model=model)
+    Eh, Ew, gh, gw, mse = ca.train_on_batch(T, xs, model=model, optim_w=optim_w, optim_h=optim_h)
+    tot, per = ca.step_energies(model, T)
+    out = dict(e0=e0, Eh=Eh, Ew=Ew, mse=mse, tot=tot, per=per,
+               h=[model.vodes[l].h.get() for l in range(model.L + 2)],
+               gw={k: gw[k] for k in model.param_keys()}, w=model.get_weights())
+    model.close()
+    return out
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_fused_and_per_op_paths_agree_at_full_size():
+    ca, mc, tc, x, h0 = _setup(200, mc_clip := 2000.0)
+    T = 20
+    a = _run(ca, mc, tc, x, h0, T, mc_clip, fused=True)
+    b = _run(ca, mc, tc, x, h0, T, mc_clip, fused=False)
+    assert np.isfinite(a["tot"]).all() and np.isfinite(b["tot"]).all()
+    assert _rel(a["e0"], a["tot"][0]) <= 1e-5          # loop step 0 vs energy() (per-op kernels), same vodes
+    assert _rel(a["tot"], b["tot"]) <= 1e-4
+    assert _rel(a["per"], b["per"]) <= 1e-4
+    assert _rel(a["Ew"], b["Ew"]) <= 1e-4 and _rel(a["mse"], b["mse"]) <= 1e-4
+    for l, (u, v) in enumerate(zip(a["h"], b["h"])):
+        assert _rel(u, v) <= 2e-4, f"vode {l}: {_rel(u, v)}"
+    gmax = max(np.abs(v).max() for v in b["gw"].values())
+    for k in b["gw"]:
+        assert np.abs(a["gw"][k] - b["gw"][k]).max() <= 3e-4 * gmax, k
+
+
+def test_images_are_independent_without_clip_at_full_size():
+    ca, mc, tc, x, h0 = _setup(200, None)
+    T = 20
+    full = _run(ca, mc, tc, x, h0, T, None)
+    lo = _run(ca, mc, tc, x, h0, T, None, sl=slice(0, 100))
+    hi = _run(ca, mc, tc, x, h0, T, None, sl=slice(100, 200))
+    for l in range(len(full["h"])):
+        got = np.concatenate([lo["h"][l], hi["h"][l]], axis=0)
+        assert _rel(got, full["h"][l]) <= 1e-5, f"vode {l}"
+    assert _rel(lo["tot"] + hi["tot"], full["tot"]) <= 1e-6      # energies add up over the batch
