@@ -18,6 +18,10 @@
 #include "common.h"
 
 #define CH 64  // streamed rows per chunk
+// 16-column output tiles per head; a head dim that is not a multiple of 16 (24 = 96 / 4 of the
+// 12-block sweep grid) computes a padded last tile -- MFMA output columns are independent, so the
+// extra columns read neighbouring LDS words and are simply never stored
+#define NT16(dh) (((dh) + 15) / 16)
 
 template <int DH>
 struct AttnSmem {
@@ -76,7 +80,7 @@ __device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const 
       float b = Pv[tt][reg];
       const float* zr = &lds[(16 * tt + 4 * grp + reg) * LD + c];
 #pragma unroll
-      for (int ct = 0; ct < DH / 16; ++ct) acc[ct] = mfma16(zr[16 * ct], b, acc[ct]);
+      for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = mfma16(zr[16 * ct], b, acc[ct]);
     }
 }
 
@@ -109,9 +113,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
   float qf[DH / 4];
   load_frag<DH>(qf, Q, ld, qrow, N, grp);
-  f32x4 oacc[DH / 16];
+  f32x4 oacc[NT16(DH)];
 #pragma unroll
-  for (int ct = 0; ct < DH / 16; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < NT16(DH); ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
 
   for (int k0 = 0; k0 < N; k0 += CH) {
@@ -147,16 +151,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     lsum = lsum * alpha + ps;
     m = mnew;
 #pragma unroll
-    for (int ct = 0; ct < DH / 16; ++ct) oacc[ct] *= alpha;
+    for (int ct = 0; ct < NT16(DH); ++ct) oacc[ct] *= alpha;
     accum_tiles<DH>(oacc, sm.s2, S, c, grp);
   }
   if (qrow < N) {
     float inv = 1.0f / lsum;
     float* orow = O + ((long long)img * N + qrow) * D + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < DH / 16; ++ct) {
+    for (int ct = 0; ct < NT16(DH); ++ct) {
       float4 v = make_float4(oacc[ct][0] * inv, oacc[ct][1] * inv, oacc[ct][2] * inv, oacc[ct][3] * inv);
-      *reinterpret_cast<float4*>(orow + 16 * ct + 4 * grp) = v;
+      if (16 * ct + 4 * grp < DH) *reinterpret_cast<float4*>(orow + 16 * ct + 4 * grp) = v;
     }
     if (grp == 0) lse2[((long long)img * N + qrow) * H + h] = m + __builtin_amdgcn_logf(lsum);
   }
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   const float l2 = (qrow < N) ? lse2[((long long)img * N + qrow) * H + h] : 0.f;
   if (qrow < N && grp == 0) delta[((long long)img * N + qrow) * H + h] = dl;
 
-  f32x4 acc[DH / 16];
+  f32x4 acc[NT16(DH)];
 #pragma unroll
-  for (int ct = 0; ct < DH / 16; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   if (qrow < N) {
     float* drow = dqkv + ((long long)img * N + qrow) * ld + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < DH / 16; ++ct) {
+    for (int ct = 0; ct < NT16(DH); ++ct) {
       float4 v = make_float4(acc[ct][0] * scale, acc[ct][1] * scale, acc[ct][2] * scale, acc[ct][3] * scale);
-      *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) = v;
+      if (16 * ct + 4 * grp < DH) *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) = v;
     }
   }
 }
@@ -250,9 +254,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
   float kf[DH / 4], vf[DH / 4];
   load_frag<DH>(kf, K, ld, krow, N, grp);
   load_frag<DH>(vf, V, ld, krow, N, grp);
-  f32x4 dk[DH / 16], dv[DH / 16];
+  f32x4 dk[NT16(DH)], dv[NT16(DH)];
 #pragma unroll
-  for (int ct = 0; ct < DH / 16; ++ct) {
+  for (int ct = 0; ct < NT16(DH); ++ct) {
     dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -286,11 +290,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
   if (krow < N) {
     float* drow = dqkv + ((long long)img * N + krow) * ld + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < DH / 16; ++ct) {
+    for (int ct = 0; ct < NT16(DH); ++ct) {
       float4 a = make_float4(dk[ct][0] * scale, dk[ct][1] * scale, dk[ct][2] * scale, dk[ct][3] * scale);
       float4 b = make_float4(dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]);
-      *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) = a;
-      *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = b;
+      if (16 * ct + 4 * grp < DH) {
+        *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) = a;
+        *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = b;
+      }
     }
   }
 }
@@ -327,6 +333,7 @@ static int run_bwd(const float* qkv, const float* O, const float* lse2, const fl
 #define DISPATCH_DH(dh, CALL)        \
   switch (dh) {                      \
     case 16: return CALL(16);        \
+    case 24: return CALL(24);        \
     case 32: return CALL(32);        \
     case 48: return CALL(48);        \
     case 64: return CALL(64);        \

@@ -225,7 +225,7 @@ int block_forward(cora_ctx* c, int G, int b0, const float* xin, float* out, int 
   {
     double fl = 4.0 * G * c->B * (double)c->N * c->N * D;
     KScope s(c, K_ATTN_FWD, fl, 4.0 * rows * 4 * D);
-    if (launch_attn_fwd(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention: head dim not supported (need 16,32,48,64,96,128)");
+    if (launch_attn_fwd(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention: head dim not supported (need 16,24,32,48,64,96,128)");
   }
   // y = x + att Wo^T
   p = gemm_base(c); p.groups = G;
@@ -563,7 +563,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   if (cfg->N != cfg->F * (cfg->Himg / cfg->patch) * (cfg->Wimg / cfg->patch)) return bad("N != F*(H/p)*(W/p)");
   if (cfg->L > 0) {
     int dh = cfg->D / cfg->H;
-    if (!(dh == 16 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return bad("head dim must be one of 16,32,48,64,96,128");
+    if (!(dh == 16 || dh == 24 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return bad("head dim must be one of 16,24,32,48,64,96,128");
     if (cfg->D > 768) return bad("hidden_size > 768 not supported by the LayerNorm kernels");
   }
   int ndev = 0;

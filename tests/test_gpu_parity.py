@@ -34,6 +34,7 @@ CASES = {
     "cfg2_shape_B4": ((3, 32, 32), 4, 64, 1, 6, 4, 5),
     "cfg3_shape_B2": ((3, 32, 32), 4, 128, 4, 12, 2, 3),
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),
+    "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
 }
