@@ -19,7 +19,7 @@ class CoraConfig(C.Structure):
         ("clip_h", C.c_float), ("clip_w", C.c_float), ("momentum", C.c_float),
         ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float),
         ("adam_wd", C.c_float), ("use_grad_norm", C.c_int32), ("grad_norm_target", C.c_float),
-        ("max_T", C.c_int32),
+        ("max_T", C.c_int32), ("use_vode_ln", C.c_int32),
     ]
 
 

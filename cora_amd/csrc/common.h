@@ -102,6 +102,7 @@ int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const f
 // ---- row-wise / element-wise ---------------------------------------------------------------------
 int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long long sParam,
                   float* xn, float* stats, int rows_per_group, int groups, int D, hipStream_t st);
+// mode 2: out = r + dy + LNbwd(dxn)   (raw cotangent, no assembly; r / dy may be null in mode 1)
 // mode 0 (LN2): out = r + LNbwd(dxn)
 // mode 1 (LN1): dxt = r + dy + LNbwd(dxn);  out = gscale[g]*(own + l1 sign(x) + 2 l2 x - dxt);
 //               red[(g) * red_stride] += out^2

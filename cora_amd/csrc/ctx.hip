@@ -45,6 +45,11 @@ struct cora_ctx {
   bool dW_owned = true;
   int64_t adam_count = 0;
   size_t oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, oWp, obp, oWout, obout;
+  // use_vode_state_layernorm: gamma / beta of the L+1 vode LayerNorms ([L+1, D] each), the normalised
+  // vodes x' the blocks read, their row statistics, and the cotangents dE/dx' of vodes 1..L+1
+  bool vln = false;
+  size_t oVg = 0, oVb = 0;
+  float *hln = nullptr, *stv = nullptr, *dxr = nullptr;
   float* pos = nullptr;
   float* WT = nullptr;      // transposed copies for the fused kernel's backward GEMMs
   size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, tWp = 0, tWout = 0, nWT = 0;
@@ -260,7 +265,9 @@ int block_forward(cora_ctx* c, int G, int b0, const float* xin, float* out, int 
 // Hand-derived VJP of G blocks with cotangent r (the next vode's error):
 //   dy = r + LN2^T(W1^T(gelu'(a) * (W2^T r)));  dx = r + dy + LN1^T(MHA^T(dy))
 // and, when gout != null, the vode gradient g_l = scale_l (e_l + reg - dx) with its sum of squares.
-int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r, const float* own, float* gout, double* red) {
+// raw: gout receives the cotangent dx itself (no gradient assembly) -- the vode LayerNorm stage finishes it.
+int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r, const float* own, float* gout, double* red,
+                   bool raw = false) {
   const int D = c->D, M = c->M, H = c->H;
   const int R = (int)c->BN;
   const long long rows = (long long)G * R;
@@ -304,7 +311,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   if (gout) {
     LnBwdP q; memset(&q, 0, sizeof q);
     q.dxn = c->dxn; q.x = xin; q.stats = c->st1; q.gamma = c->W + c->oLn1g + (size_t)b0 * D; q.sParam = D;
-    q.r = r; q.dy = c->dy; q.own = own; q.out = gout; q.rows_per_group = R; q.groups = G; q.D = D; q.mode = 1;
+    q.r = r; q.dy = c->dy; q.own = own; q.out = gout; q.rows_per_group = R; q.groups = G; q.D = D; q.mode = raw ? 2 : 1;
     q.gscale = c->gscale + b0; q.l1 = c->cfg.l1; q.l2 = c->cfg.l2; q.red = red; q.red_stride = 1;
     KScope s(c, K_LN_BWD, 0, 28.0 * rows * D);
     if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: shape not supported");
@@ -368,15 +375,25 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
 }
 
 // energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
+// vodes 1..L+1 through their LayerNorms (use_vode_state_layernorm, :232-241): hln = LN_v(h_v)
+void vode_ln_forward(cora_ctx* c) {
+  const int L = c->L, D = c->D;
+  KScope s(c, K_LN_FWD, 0, 8.0 * (L + 1) * c->nl);
+  launch_ln_fwd(vode_ptr(c, c->Hs, 1), c->W + c->oVg, c->W + c->oVb, D, c->hln, c->stv, (int)c->BN, L + 1, D, c->st);
+}
+// what block g / the output projection read: the vode itself, or its normalised copy
+const float* vode_in(cora_ctx* c, int l) { return c->vln ? c->hln + (long long)(l - 1) * c->nl : vode_ptr(c, c->Hs, l); }
+
 int errors_pass(cora_ctx* c, int slot) {
   const int L = c->L;
   double* en = c->energies + (long long)slot * (L + 3);
+  if (c->vln) vode_ln_forward(c);
   patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
   if (L > 0) {
-    int rc = block_forward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
+    int rc = block_forward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
     if (rc) return rc;
   }
-  out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
+  out_proj(c, vode_in(c, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
   return 0;
 }
 
@@ -419,12 +436,25 @@ int infer_grad_step(cora_ctx* c, int t) {
   p = gemm_base(c, 1);
   p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
   p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
-  p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
-  p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
+  if (c->vln) {   // cotangent w.r.t. the NORMALISED vode L+1; LN_L^T and the assembly follow below
+    p.C = c->dxr + (long long)L * c->nl; p.mode = OUT_STORE;
+  } else {
+    p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
+    p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
+  }
   run_gemm(c, p, false, true);
   if (L > 0) {
-    rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
+    if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true);
+    else rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
     if (rc) return rc;
+  }
+  if (c->vln) {   // g_v = s_v (e_v + reg - LN_{v-1}^T dx'_v) for v = 1..L+1 in one grouped pass
+    LnBwdP q; memset(&q, 0, sizeof q);
+    q.dxn = c->dxr; q.x = vode_ptr(c, c->Hs, 1); q.stats = c->stv; q.gamma = c->W + c->oVg; q.sParam = c->D;
+    q.own = err_ptr(c, 1); q.out = vode_ptr(c, c->Gs, 1); q.rows_per_group = (int)c->BN; q.groups = L + 1; q.D = c->D; q.mode = 1;
+    q.gscale = c->gscale; q.l1 = c->cfg.l1; q.l2 = c->cfg.l2; q.red = ss + 8; q.red_stride = 1;
+    KScope s(c, K_LN_BWD, 0, 20.0 * (L + 1) * c->nl);
+    if (launch_ln_bwd(q, c->st)) FAIL(-3, "vode layer norm backward: shape not supported");
   }
   }
   return 0;
@@ -494,15 +524,24 @@ int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
     if (launch_chain(f, into_vodes ? 1 : 0, c->st)) FAIL(-3, "chain kernel launch failed");
     return 0;
   }
+  // with vode LayerNorms the vode keeps u (INIT: h := u) and hands LN(u) on, :232-241
+  auto hand_on = [&](const float* u, int i) -> const float* {
+    if (!c->vln) return u;
+    float* dst = c->hln + (long long)i * c->nl;
+    KScope s(c, K_LN_FWD, 0, 8.0 * c->nl);
+    launch_ln_fwd(u, c->W + c->oVg + (size_t)i * c->D, c->W + c->oVb + (size_t)i * c->D, c->D, dst,
+                  c->stv + 2LL * i * c->BN, (int)c->BN, 1, c->D, c->st);
+    return dst;
+  };
   float* cur = into_vodes ? vode_ptr(c, c->Hs, 1) : c->ua;
   patch_proj(c, vode_ptr(c, c->Hs, 0), cur, OUT_STORE, nullptr, nullptr);
   for (int i = 0; i < L; ++i) {
     float* nxt = into_vodes ? vode_ptr(c, c->Hs, i + 2) : (cur == c->ua ? c->ub : c->ua);
-    int rc = block_forward(c, 1, i, cur, nxt, OUT_STORE, nullptr, nullptr);
+    int rc = block_forward(c, 1, i, hand_on(cur, i), nxt, OUT_STORE, nullptr, nullptr);
     if (rc) return rc;
     cur = nxt;
   }
-  out_proj(c, cur, c->z, OUT_STORE, nullptr, nullptr);
+  out_proj(c, hand_on(cur, L), c->z, OUT_STORE, nullptr, nullptr);
   return 0;
 }
 
@@ -589,13 +628,15 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->oWqkv = o; o += L * 3 * D * D; c->oWo = o; o += L * D * D;
   c->oW1 = o; o += L * M * D; c->ob1 = o; o += L * M; c->oW2 = o; o += L * D * M; c->ob2 = o; o += L * D;
   c->oWp = o; o += D * P; c->obp = o; o += D; c->oWout = o; o += P * D; c->obout = o; o += P;
+  c->vln = cfg->use_vode_ln != 0;
+  if (c->vln) { c->oVg = o; o += (size_t)(L + 1) * D; c->oVb = o; o += (size_t)(L + 1) * D; }
   c->nW = o;
 
   int rc = 0;
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
-  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && getenv("CORA_NO_FUSED") == nullptr);
+  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && getenv("CORA_NO_FUSED") == nullptr);
   if (c->fused) {
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
@@ -606,6 +647,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
+  if (c->vln) { DA(c->hln, (long long)(L + 1) * c->nl); DA(c->stv, 2LL * (L + 1) * c->BN); DA(c->dxr, (long long)(L + 1) * c->nl); }
   DA(c->xp, c->n0); DA(c->ximg, c->nImg);
   c->Gmax = c->L > 0 ? c->L : 1;
   const long long rows = (long long)c->Gmax * c->BN;
@@ -697,6 +739,13 @@ int cora_weight_offset(const cora_ctx* cc, const char* key, size_t* offset, size
   if (k == ".patch_projection.nn.bias") return set(c->obp, D);
   if (k == ".output_projection.nn.weight") return set(c->oWout, P * D);
   if (k == ".output_projection.nn.bias") return set(c->obout, P);
+  if (c->vln) {
+    int vi = -1; char leaf[16] = {0};
+    if (sscanf(k.c_str(), ".vode_output_layernorms[%d].nn.%15s", &vi, leaf) == 2 && vi >= 0 && vi <= c->L) {
+      if (!strcmp(leaf, "weight")) return set(c->oVg + (size_t)vi * D, D);
+      if (!strcmp(leaf, "bias")) return set(c->oVb + (size_t)vi * D, D);
+    }
+  }
   const char* pre = ".transformer_blocks[";
   if (k.compare(0, strlen(pre), pre) == 0) {
     size_t close = k.find(']');
@@ -930,13 +979,14 @@ int enqueue_wgrad(cora_ctx* c) {
   }
   wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);
   if (!c->fused) { KScope s(c, K_OTHER, 0, 4.0 * R * D); launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st); }
-  wgrad_gemm(c, 1, err_ptr(c, L + 2), P, 0, vode_ptr(c, c->Hs, L + 1), D, 0, c->dW + c->oWout, 0, 0);
+  wgrad_gemm(c, 1, err_ptr(c, L + 2), P, 0, vode_in(c, L + 1), D, 0, c->dW + c->oWout, 0, 0);
   if (!c->fused) { KScope s(c, K_OTHER, 0, 4.0 * R * P); launch_colsum(err_ptr(c, L + 2), nullptr, nullptr, c->dW + c->obout, 0, R, 1, P, -1.f, c->st); }
   if (L > 0) {
     const float* r = err_ptr(c, 2);
-    const float* xin = vode_ptr(c, c->Hs, 1);
+    const float* xin = vode_in(c, 1);
     if (!c->fused) {
-      rc = block_backward(c, L, 0, xin, r, nullptr, nullptr, nullptr);
+      // with vode LayerNorms the cotangents dE/dx' are needed too (their gamma / beta gradients)
+      rc = block_backward(c, L, 0, xin, r, nullptr, c->vln ? c->dxr : nullptr, nullptr, c->vln);
       if (rc) return rc;
     }
     const long long sD = (long long)R * D, sM = (long long)R * M, s3 = (long long)R * 3 * D;
@@ -953,6 +1003,15 @@ int enqueue_wgrad(cora_ctx* c) {
       launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
       launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
     }
+  }
+  if (c->vln) {   // vode LayerNorm parameters: d gamma_v = -sum dx'_v * xhat_v, d beta_v = -sum dx'_v
+    GemmP p = gemm_base(c, 1);
+    p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = c->dxr + (long long)L * c->nl;
+    p.R = R; p.O = D; p.K = P; p.lda = P; p.ldb = D; p.ldc = D; p.mode = OUT_STORE;
+    run_gemm(c, p, false, true);                                  // dx'_{L+1} = e_img Wout
+    KScope s(c, K_OTHER, 0, 12.0 * (L + 1) * R * D);
+    launch_colsum(c->dxr, vode_ptr(c, c->Hs, 1), c->stv, c->dW + c->oVg, D, R, L + 1, D, -1.f, c->st);
+    launch_colsum(c->dxr, nullptr, nullptr, c->dW + c->oVb, D, R, L + 1, D, -1.f, c->st);
   }
   return 0;
 }
@@ -1330,7 +1389,7 @@ int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, 
   if (E) *E = tot;
   if (per_layer) memcpy(per_layer, en.data(), sizeof(double) * en.size());
   if (xhat) {
-    out_proj(c, vode_ptr(c, c->Hs, L + 1), c->z, OUT_STORE, nullptr, nullptr);
+    out_proj(c, vode_in(c, L + 1), c->z, OUT_STORE, nullptr, nullptr);   // hln is current: errors_pass just ran
     return download_image(c, c->z, xhat, n);
   }
   return 0;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
     int cidx = 64 * i + 4 * sub;
     if (live && cidx < D) {
       const long long idx = row * D + cidx;
-      float4 rr = *reinterpret_cast<const float4*>(p.r + idx);
+      float4 rr = p.r ? *reinterpret_cast<const float4*>(p.r + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
       float dx[4] = {rstd * (dh[i].x - m1 - xh[i].x * m2), rstd * (dh[i].y - m1 - xh[i].y * m2),
                      rstd * (dh[i].z - m1 - xh[i].z * m2), rstd * (dh[i].w - m1 - xh[i].w * m2)};
       float rv[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -116,8 +116,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
       if (p.mode == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[j] = rv[j] + dx[j];
-      } else {
+      } else if (p.mode == 2) {   // raw cotangent r + dy + LN^T(dxn), no gradient assembly
         float4 dy4 = *reinterpret_cast<const float4*>(p.dy + idx);
+        out[0] = rv[0] + dy4.x + dx[0]; out[1] = rv[1] + dy4.y + dx[1];
+        out[2] = rv[2] + dy4.z + dx[2]; out[3] = rv[3] + dy4.w + dx[3];
+      } else {
+        float4 dy4 = p.dy ? *reinterpret_cast<const float4*>(p.dy + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 ow4 = *reinterpret_cast<const float4*>(p.own + idx);
         float4 xv4 = *reinterpret_cast<const float4*>(p.x + idx);
         float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};

@@ -21,7 +21,8 @@ import numpy as np
 from . import _lib
 from .config import TransformerConfig
 from .optim import Optim, adamw, lr_at, sgd
-from .params import BLOCK_LEAVES, K_BOUT, K_BP, K_WOUT, K_WP, block_key, init_params, param_shapes, vode_key
+from .params import (BLOCK_LEAVES, K_BOUT, K_BP, K_WOUT, K_WP, block_key, init_params, param_shapes, vln_key,
+                     vode_key)
 from .posenc import create_positional_encoding
 
 STATUS_FORWARD = "forward"
@@ -139,8 +140,6 @@ class TransformerDecoder:
     def __init__(self, config: TransformerConfig, *, seed: int = 42, device: int = 0, max_T: int = 64,
                  compute_dtype: str = "fp32"):
         _lib.load()                      # fail loudly if the HIP library is missing
-        if config.use_vode_state_layernorm:
-            raise NotImplementedError("use_vode_state_layernorm is outside the implemented hot path")
         if compute_dtype not in ("fp32", "bf16"):
             raise ValueError("compute_dtype must be 'fp32' (parity path) or 'bf16' (opt-in: bf16 MFMA operands)")
         self._dtype_mode = 1 if compute_dtype == "bf16" else 0
@@ -157,8 +156,9 @@ class TransformerDecoder:
             self._C, self._Himg, self._Wimg = c.image_shape
         self.N, self.P, self.D, self.M, self.L, self.H = (c.num_patches, c.patch_dim, c.hidden_size,
                                                           c.mlp_hidden_dim, c.num_blocks, c.num_heads)
-        self._shapes = dict(param_shapes(self.P, self.D, self.M, self.L))
-        self._host_w: Dict[str, np.ndarray] = init_params(self.P, self.D, self.M, self.L, seed)
+        vln = bool(c.use_vode_state_layernorm)
+        self._shapes = dict(param_shapes(self.P, self.D, self.M, self.L, vln))
+        self._host_w: Dict[str, np.ndarray] = init_params(self.P, self.D, self.M, self.L, seed, vln)
         self._rng = np.random.default_rng(seed + 1)
         self.positional_embedding = create_positional_encoding(
             image_shape=c.image_shape, hidden_size=c.hidden_size, patch_size=c.patch_size,
@@ -169,7 +169,10 @@ class TransformerDecoder:
         LP = lambda k: LayerParam(self, k, self._shapes[k])
         self.patch_projection = _Layer(_NN(weight=LP(K_WP), bias=LP(K_BP)))
         self.output_projection = _Layer(_NN(weight=LP(K_WOUT), bias=LP(K_BOUT)))
-        self.vode_output_layernorms: list = []
+        # LayerNorms on what vodes 1..L+1 hand on (reference :212-218); per-op kernels only
+        self.vode_output_layernorms: list = (
+            [_Layer(_NN(weight=LP(vln_key(i, "weight")), bias=LP(vln_key(i, "bias")))) for i in range(self.L + 1)]
+            if vln else [])
         self._ctx = None
         self._B = None
         self._offsets: Dict[str, tuple] = {}
@@ -197,7 +200,8 @@ class TransformerDecoder:
             l1=float(c.intermediate_l1_coeff), l2=float(c.intermediate_l2_coeff),
             clip_h=0.0, clip_w=0.0, momentum=0.0, adam_b1=0.9, adam_b2=0.999, adam_eps=1e-8,
             adam_wd=0.0, use_grad_norm=int(bool(c.use_vode_grad_norm)),
-            grad_norm_target=float(c.vode_grad_norm_target), max_T=self.max_T)
+            grad_norm_target=float(c.vode_grad_norm_target), max_T=self.max_T,
+            use_vode_ln=int(bool(c.use_vode_state_layernorm)))
 
     def _ensure_ctx(self, B: int):
         if self._ctx is not None:

@@ -33,7 +33,13 @@ def vode_key(l: int) -> str:
     return f".vodes[{l}].h"
 
 
-def param_shapes(P: int, D: int, M: int, L: int) -> List[Tuple[str, Tuple[int, ...]]]:
+def vln_key(i: int, leaf: str) -> str:
+    """LayerNorm applied to what vode i+1 hands on (use_vode_state_layernorm,
+    /root/reference/src/decoder_transformer.py:212-218); leaf = "weight" | "bias"."""
+    return f".vode_output_layernorms[{i}].nn.{leaf}"
+
+
+def param_shapes(P: int, D: int, M: int, L: int, vode_ln: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
     """(key, shape) of every LayerParam, in the model's attribute order."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
     for i in range(L):
@@ -47,21 +53,24 @@ def param_shapes(P: int, D: int, M: int, L: int) -> List[Tuple[str, Tuple[int, .
         }
         out += [(block_key(i, leaf), shp[leaf]) for leaf in BLOCK_LEAVES]
     out += [(K_WP, (D, P)), (K_BP, (D,)), (K_WOUT, (P, D)), (K_BOUT, (P,))]
+    if vode_ln:
+        for i in range(L + 1):
+            out += [(vln_key(i, "weight"), (D,)), (vln_key(i, "bias"), (D,))]
     return out
 
 
-def init_params(P: int, D: int, M: int, L: int, seed: int = 42) -> Dict[str, np.ndarray]:
+def init_params(P: int, D: int, M: int, L: int, seed: int = 42, vode_ln: bool = False) -> Dict[str, np.ndarray]:
     """equinox 0.11.8 defaults: Linear weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)); LayerNorm
     gamma=1, beta=0.  (The reference draws from the JAX threefry stream of pcx's RKG; that bit
     stream is not reproduced -- weights are inputs of the step)"""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    shapes = dict(param_shapes(P, D, M, L))
+    shapes = dict(param_shapes(P, D, M, L, vode_ln))
     for key, shp in shapes.items():
-        if "layer_norm" in key:
+        if "layer_norm" in key or "layernorms" in key:
             out[key] = (np.ones if key.endswith("weight") else np.zeros)(shp, dtype=np.float32)
     for key, shp in shapes.items():
-        if key.endswith(".weight") and "layer_norm" not in key:
+        if key.endswith(".weight") and "layer_norm" not in key and "layernorms" not in key:
             lim = 1.0 / np.sqrt(shp[1])
             out[key] = rng.uniform(-lim, lim, size=shp).astype(np.float32)
             bkey = key[:-len("weight")] + "bias"

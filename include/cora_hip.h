@@ -61,6 +61,9 @@ typedef struct cora_config {
   int32_t use_grad_norm;    /* use_vode_grad_norm (:353-389)                     */
   float   grad_norm_target; /* vode_grad_norm_target                             */
   int32_t max_T;         /* largest T any call will use (sizes the energy log)   */
+  int32_t use_vode_ln;   /* use_vode_state_layernorm (:212-218, 232-241): what vodes 1..L+1 hand on goes
+                          * through its own LayerNorm (keys .vode_output_layernorms[i].nn.weight/bias).
+                          * Per-op kernels only. */
 } cora_config;
 
 /* Results of one step; replaces the 5-tuple returned by train_on_batch

@@ -120,6 +120,11 @@ K_WP, K_BP = ".patch_projection.nn.weight", ".patch_projection.nn.bias"
 K_WOUT, K_BOUT = ".output_projection.nn.weight", ".output_projection.nn.bias"
 
 
+def vln_keys(i: int):
+    """Vode-state LayerNorm i (after vode i+1), src/decoder_transformer.py:212-218."""
+    return f".vode_output_layernorms[{i}].nn.weight", f".vode_output_layernorms[{i}].nn.bias"
+
+
 # ----------------------------------------------------------------------------------------------
 # elementary ops
 # ----------------------------------------------------------------------------------------------
@@ -207,14 +212,22 @@ def predictions(h: Sequence[torch.Tensor], W, pos, dims: Dims, chain: bool = Fal
     Returns u_1..u_{L+2}; u_{L+2} is the image prediction.  chain=False: status None, block i reads
     h_{i+1} (pcx/predictive_coding/_vode.py:223-236).  chain=True: rule 'h -> u'
     (src/decoder_transformer.py:167-168,175-176): each vode hands its u downstream."""
+    vln = vln_keys(0)[0] in W            # use_vode_state_layernorm: the value a vode hands on is normalised, :232-241
+
+    def hand_on(x, i):
+        if not vln:
+            return x
+        kg, kb = vln_keys(i)
+        return layer_norm(x, W[kg], W[kb])
+
     us = []
     u = linear(h[0], W[K_WP], W[K_BP]) + pos
     us.append(u)
-    x = u if chain else h[1]
+    x = hand_on(u if chain else h[1], 0)
     for i in range(dims.L):
         u = x + transformer_block(x, W, i, dims.H)   # double residual, :238
         us.append(u)
-        x = u if chain else h[i + 2]
+        x = hand_on(u if chain else h[i + 2], i + 1)
     z = linear(x, W[K_WOUT], W[K_BOUT])
     us.append(unpatchify(z, dims))
     return us

@@ -209,11 +209,21 @@ def test_two_batches_persistent_state_and_adam():
     model.close()
 
 
-def test_init_forward_energy_api():
+@pytest.mark.parametrize("name", ["0block", "tiny_2block_h2", "cfg2_shape_B4", "cfg5_video_small"])
+def test_vode_state_layernorm(name):
+    """use_vode_state_layernorm (src/decoder_transformer.py:212-218, 232-241): what vodes 1..L+1 hand on goes
+    through a LayerNorm of its own; L+1 extra (gamma, beta) pairs in the parameter tree and in dE/dW.  The
+    cfg2 shape takes the per-op path here (the fused kernel is built for the flag's default, off)."""
+    errs = run_case(name, vode_ln=True, l1=1e-3, l2=1e-3, clip_h=5.0)
+    assert any("vode_output_layernorms" in k for k in errs)
+
+
+@pytest.mark.parametrize("vode_ln", [False, True])
+def test_init_forward_energy_api(vode_ln):
     """INIT forward (h_l := u_l chained), status-None energy() and status-"forward" reconstruction."""
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES["tiny_2block_h2"]
-    case = make_case(shape, p, D, H, L, B, seed=11)
+    case = make_case(shape, p, D, H, L, B, seed=11, vode_ln=vode_ln)
     model, _, _ = build_model(case)
     model.init_vodes(B, h0=case["h0"])
     href = R.init_vodes(case["h0"], case["W"], case["pos"], case["dims"])

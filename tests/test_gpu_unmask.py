@@ -35,9 +35,19 @@ def _check(name, errs, floor):
 @pytest.mark.parametrize("name", list(SHAPES))
 @pytest.mark.parametrize("lower_half,alpha,clip_h", [(True, 1.0, 2000.0), (False, 0.6, 3.0)])
 def test_unmask_with_corruption(name, lower_half, alpha, clip_h):
+    _unmask_with_corruption(name, lower_half, alpha, clip_h, False)
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_unmask_vode_state_layernorm(name):
+    """The same loop with use_vode_state_layernorm (:232-241) -- per-op path for both shapes."""
+    _unmask_with_corruption(name, False, 0.6, 3.0, True)
+
+
+def _unmask_with_corruption(name, lower_half, alpha, clip_h, vode_ln):
     import cora_amd as ca
     shape, p, D, H, L, B, T = SHAPES[name]
-    case = make_case(shape, p, D, H, L, B, seed=21, clip_h=clip_h)
+    case = make_case(shape, p, D, H, L, B, seed=21, clip_h=clip_h, vode_ln=vode_ln)
     model, optim_w, optim_h = build_model(case)
     model.config.use_lower_half_mask = lower_half
     model.config.inference_clamp_alpha = alpha

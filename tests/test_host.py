@@ -134,9 +134,14 @@ def test_create_fails_loudly_without_gpu_or_on_bad_config():
             m.init_vodes(2)
 
 
-def test_unsupported_modes_raise():
-    with pytest.raises(NotImplementedError):
-        ca.TransformerDecoder(ca.create_config(use_vode_state_layernorm=True))
+def test_vode_layernorm_inventory():
+    """use_vode_state_layernorm adds L+1 LayerNorms to the parameter tree (:212-218)."""
+    m = ca.TransformerDecoder(ca.create_config(hidden_size=16, num_heads=1, num_blocks=2, use_vode_state_layernorm=True))
+    assert len(m.vode_output_layernorms) == 3
+    keys = m.param_keys()
+    assert ".vode_output_layernorms[2].nn.weight" in keys and ".vode_output_layernorms[0].nn.bias" in keys
+    m0 = ca.TransformerDecoder(ca.create_config(hidden_size=16, num_heads=1, num_blocks=2))
+    assert len(m0.vode_output_layernorms) == 0
 
 
 def test_make_mask_and_psnr():

@@ -97,6 +97,25 @@ def test_autograd_matches_hand_vjp(shape, p, D, H, L, B, l1, l2, clip):
         np.testing.assert_allclose(wg[k], out["w_grad"][k], rtol=1e-8, atol=1e-10)
 
 
+def test_vode_layernorm_weight_gradient_by_finite_differences():
+    """use_vode_state_layernorm (:212-218, 232-241): the oracle's dE/dW of the extra LayerNorms against a
+    central difference of its own energy at the final vodes (no hand VJP exists for this option)."""
+    case = make_case((3, 16, 16), 4, 32, 2, 2, 2, seed=4, vode_ln=True)
+    W = {k: v.astype(np.float64) for k, v in case["W"].items()}
+    h = [t.astype(np.float64) for t in case["h"]]
+    out = R.train_on_batch(2, case["x"], W, h, case["pos"], case["dims"], case["hp"], [0.095] * 2, 1e-3)
+    assert sum("vode_output_layernorms" in k for k in out["w_grad"]) == 6
+    E0 = out["final_w_energy"]
+    for k in (".vode_output_layernorms[0].nn.weight", ".vode_output_layernorms[1].nn.bias", ".vode_output_layernorms[2].nn.weight"):
+        for j in (0, 17):
+            Wp = {a: b.copy() for a, b in W.items()}; Wm = {a: b.copy() for a, b in W.items()}
+            Wp[k][j] += 1e-6; Wm[k][j] -= 1e-6
+            Ep = R.energy_and_prediction(out["h"], Wp, case["pos"], case["x"], case["dims"], case["hp"])[0]
+            Em = R.energy_and_prediction(out["h"], Wm, case["pos"], case["x"], case["dims"], case["hp"])[0]
+            assert (Ep - Em) / 2e-6 == pytest.approx(out["w_grad"][k][j], rel=1e-5, abs=1e-7)
+    assert E0 == pytest.approx(R.energy_and_prediction(out["h"], W, case["pos"], case["x"], case["dims"], case["hp"])[0], rel=1e-12)
+
+
 def test_layer_scaling_exponents():
     # /root/reference/src/decoder_transformer.py:321-341: factor base^{(L+1) - l}
     dims = R.Dims((3, 8, 8), 4, 16, 1, 2)

@@ -7,14 +7,14 @@ from oracle import pcvit_ref as R
 
 def make_case(image_shape, patch, D, H, L, B, seed=0, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0,
               momentum=0.4, scale_base=1.25, use_scaling=True, theta=10000, h_noise=0.05,
-              use_grad_norm=False, grad_norm_target=1.0):
+              use_grad_norm=False, grad_norm_target=1.0, vode_ln=False):
     from cora_amd.params import init_params
     from cora_amd.posenc import create_positional_encoding
     dims = R.Dims(tuple(image_shape), patch, D, H, L)
     rng = np.random.default_rng(seed)
-    W = init_params(dims.P, D, dims.M, L, seed + 7)
+    W = init_params(dims.P, D, dims.M, L, seed + 7, vode_ln=vode_ln)
     for k in W:                       # LayerNorm params away from the trivial (1, 0)
-        if "layer_norm" in k:
+        if "layer_norm" in k or "layernorms" in k:
             W[k] = (W[k] + 0.1 * rng.standard_normal(W[k].shape)).astype(np.float32)
     pos = create_positional_encoding(tuple(image_shape), D, patch, theta=theta)
     x = rng.uniform(0, 1, (B,) + tuple(image_shape)).astype(np.float32)
@@ -35,7 +35,8 @@ def build_model(case, max_T=64, compute_dtype="fp32", ipc=False):
         inference_lr_scale_base=hp.scale_base, update_weights_every_inference_step=ipc,
         use_status_init_in_training=False, use_status_init_in_unmasking=False,
         intermediate_l1_coeff=hp.l1, intermediate_l2_coeff=hp.l2,
-        use_vode_grad_norm=hp.use_grad_norm, vode_grad_norm_target=hp.grad_norm_target)
+        use_vode_grad_norm=hp.use_grad_norm, vode_grad_norm_target=hp.grad_norm_target,
+        use_vode_state_layernorm=any("vode_output_layernorms" in k for k in case["W"]))
     model = ca.TransformerDecoder(cfg, max_T=max_T, compute_dtype=compute_dtype)
     model.positional_embedding = case["pos"]
     model.set_weights(case["W"])
