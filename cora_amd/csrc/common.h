@@ -167,6 +167,7 @@ struct FusedP {
   double* energy;   // STORE pass: per-vode energies accumulated here directly (null in the inference step)
   double* esens;    // inference step: 8 slots for the sensory energy (the vode-step kernel derives the rest from e)
   int B; float l1, l2;
+  int H;            // heads: 1, 2 or 4 (head dim 64, 32, 16)
   // edge layers (vode 0 / 1 and vode L+1 / sensory), one extra workgroup per image
   int L; float s0;
   const float* H0; const float* XP; const float* pos;
@@ -174,7 +175,7 @@ struct FusedP {
   long long oWp, obp, oWout, obout, tWp, tWout;
   // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
   float *S_xn1, *S_att, *S_xn2, *S_a, *S_da, *S_dy, *S_dqkv;
-  float* S_stash;   // [L*B*N, 3D]: q | P | y parked between forward and backward
+  float* S_stash;   // [L*B*N, (2+H) D]: q | P (one 64-key row per head) | y parked between forward and backward
   float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients land here (null otherwise)
   float* colpart;   // MODE_STORE: per-wave column sums of the block workgroups (fused_colpart_floats)
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error

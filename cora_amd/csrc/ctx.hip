@@ -369,7 +369,7 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
   f.S_xn1 = c->xn1; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_a = c->a; f.S_da = c->da;
   f.S_dy = c->dy; f.S_dqkv = c->dqkv;
-  f.S_stash = c->stash;
+  f.S_stash = c->stash; f.H = c->H;
   f.Z = c->z; f.mse = nullptr;
   f.dbg = c->dbg;
 }
@@ -598,6 +598,11 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return bad("D, P and M must be multiples of 4 (16-byte rows)");
   if (((long long)cfg->B * cfg->N) % 4) return bad("B*N must be a multiple of 4");
   if (cfg->L + 3 > 64) return bad("too many blocks (L <= 61)");
+  {   // the GEMM epilogue addresses one group's output with 32-bit element offsets
+    long long widest = cfg->M > 3 * cfg->D ? cfg->M : 3 * cfg->D;
+    if (cfg->P > widest) widest = cfg->P;
+    if ((long long)cfg->B * cfg->N * widest >= (1LL << 31)) return bad("B*N*max(M, 3D, P) must stay below 2^31 elements");
+  }
   if (cfg->P != cfg->patch * cfg->patch * cfg->C) return bad("P != patch*patch*C");
   if (cfg->N != cfg->F * (cfg->Himg / cfg->patch) * (cfg->Wimg / cfg->patch)) return bad("N != F*(H/p)*(W/p)");
   if (cfg->L > 0) {
@@ -636,7 +641,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
-  c->fused = (c->N == 64 && c->D == 64 && c->H == 1 && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && getenv("CORA_NO_FUSED") == nullptr);
+  c->fused = (c->N == 64 && c->D == 64 && (c->H == 1 || c->H == 2 || c->H == 4) && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && getenv("CORA_NO_FUSED") == nullptr);
   if (c->fused) {
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
@@ -656,7 +661,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->da, rows * M); DA(c->dzn, rows * D); DA(c->dy, rows * D); DA(c->dO, rows * D); DA(c->delta, rows * c->H);
   DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
   DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
-  if (c->fused) DA(c->stash, rows * 3 * D);
+  if (c->fused) DA(c->stash, rows * (2 + c->H) * D);
   DA(c->gscale, 64); DA(c->eta_dev, c->Tmax + 1);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;

@@ -63,6 +63,40 @@ __device__ __forceinline__ void accum_tile(const float* __restrict__ t, const fl
     }
 }
 
+// Head-restricted variants (H heads of width 64 / H = 16 NC columns): the contraction of gemm_tile_h
+// and the output columns of accum_tile_h cover column groups ct0 .. ct0 + NC - 1 only.  xf / the
+// caller's result stay indexed by the global column group, so a head fills its own slice of a row.
+template <int NC>
+__device__ __forceinline__ void gemm_tile_h(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp, int ct0) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ct = ct0 + c;
+    float4 a[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LD + 16 * ct + 4 * grp]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * ct + 0], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * ct + 1], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * ct + 2], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * ct + 3], acc[ot]);
+  }
+}
+template <int NC>
+__device__ __forceinline__ void accum_tile_h(const float* __restrict__ t, const float* pf, f32x4* acc, int i, int grp, int ct0) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float* row = &t[(16 * tt + 4 * grp + reg) * LD + i + 16 * ct0];
+      float b = pf[4 * tt + reg];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(row[16 * c], b, acc[c]);
+    }
+}
+
 __device__ __forceinline__ float grp_sum(float v) {
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
@@ -246,7 +280,7 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   }
 }
 
-// One transformer block of one image (D = 64, M = 256, N = 64, H = 1).
+// One transformer block of one image (D = 64, M = 256, N = 64, H = 1, 2 or 4 heads).
 //   MODE_INFER: x = h_{g+1} from HBM; writes e_{g+2}, its energy and J^T e (the inference step)
 //   MODE_STORE: the same, and also leaves every tensor the weight-gradient GEMMs need in HBM
 //   MODE_CHAIN: x comes in registers (xio), forward only, the prediction u goes back in xio
@@ -277,9 +311,11 @@ enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
 #endif
 
 
-template <int MODE>
+template <int MODE, int H>
 __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, int b, float* xio) {
   constexpr int D = 64, M = 256;
+  constexpr int NCH = 4 / H;                 // 16-column groups per head (head dim 64 / H)
+  constexpr float qscale = (H == 1) ? 0.125f : (H == 2 ? 0.17677669529663687f : 0.25f);   // 1 / sqrt(head dim)
   // 4 tiles (69.6 KB) so two workgroups share a CU: K and V persist from the forward into the
   // backward; the weight double buffer is only live during GEMM phases and is reused for Q and dO
   // (all 64 tokens) during the attention backward.
@@ -288,7 +324,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   float* wbuf = lds + 2 * TILE;          // 2 tiles
   float* bufQ = lds + 2 * TILE;          // aliases wbuf[0]
   float* bufDO = lds + 3 * TILE;         // aliases wbuf[1]
-  float* rowc = lds + 4 * TILE;          // lse2[64], delta[64]
+  float* rowc = lds + 4 * TILE;          // lse2[H][64], delta[H][64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, grp = lane >> 4;
@@ -302,9 +338,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
   // in the forward and only needed again in the backward (q, P, y, the MLP pre-activation a) are
   // parked in an L2-resident stash instead of registers and reloaded at their point of use.
-  float* st_q = p.S_stash + srow_g * (3 * D);
-  float* st_p = st_q + D;
-  float* st_y = st_q + 2 * D;
+  float* st_q = p.S_stash + srow_g * ((2 + H) * D);
+  float* st_p = st_q + D;                // H x 64: one row of P per head
+  float* st_y = st_q + (1 + H) * D;
   float* st_a = p.S_a + srow_g * M;
 
   const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
@@ -352,7 +388,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   PREFETCH(Wqkv, D);               // tile 0: Wq
   const float* t;
   f32x4 acc[4];
-  const float sc = 0.125f * CORA_LOG2E;   // 1/sqrt(64) in base-2 units
+  const float sc = qscale * CORA_LOG2E;   // 1/sqrt(head dim) in base-2 units
 
   STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
@@ -402,9 +438,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     STAMP(2);
     // attention: S[key][q] -> softmax over keys -> O
     float of[16];
-    {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
       float pf[16];
-      zero4(acc); gemm_tile(bufK, qf, acc, i, grp); unpack(acc, pf);
+      zero4(acc); gemm_tile_h<NCH>(bufK, qf, acc, i, grp, NCH * h); unpack(acc, pf);
       float mx = -INFINITY;
 #pragma unroll
       for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
@@ -416,11 +453,18 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       const float inv = 1.0f / ls;
 #pragma unroll
       for (int k = 0; k < 16; ++k) pf[k] *= inv;
-      if (grp == 0) rowc[16 * w + i] = mx + __builtin_amdgcn_logf(ls);
-      if (MODE != MODE_CHAIN) store_rowT(pf, st_p, grp);
-      zero4(acc); accum_tile(bufV, pf, acc, i, grp); unpack(acc, of);
-      if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
+      if (grp == 0) rowc[64 * h + 16 * w + i] = mx + __builtin_amdgcn_logf(ls);
+      if (MODE != MODE_CHAIN) store_rowT(pf, st_p + 64 * h, grp);
+      f32x4 oa[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) oa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accum_tile_h<NCH>(bufV, pf, oa, i, grp, NCH * h);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) of[4 * (NCH * h + c) + reg] = oa[c][reg];
     }
+    if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
     STAMP(3);
     PUBLISH(1, t); PREFETCH(W1, D);   // Wo; -> tile 4: W1[0]
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
@@ -571,48 +615,71 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     load_rowT(qf, st_q, D, grp);
     store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
     STAMP(9);
-    // attention backward, pass A (own queries): dP, delta, dS, dQ
-    float pf[16], dp[16];
-    load_rowT(pf, st_p, D, grp);
-    zero4(acc); gemm_tile(bufV, dof, acc, i, grp); unpack(acc, dp);     // dP[key][q] = V[key] . dO[q]
-    float dl = 0.f;
+    // attention backward, pass A (own queries): dP, delta, dS, dQ -- head by head
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
-    dl = grp_sum(dl);                                                    // delta = sum_key P dP = dO . O
-    if (grp == 0) rowc[64 + 16 * w + i] = dl;
+    for (int h = 0; h < H; ++h) {
+      float pf[16], dp[16];
+      load_rowT(pf, st_p + 64 * h, D, grp);
+      zero4(acc); gemm_tile_h<NCH>(bufV, dof, acc, i, grp, NCH * h); unpack(acc, dp);   // dP[key][q] = V[key] . dO[q]
+      float dl = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);           // dS
-    zero4(acc); accum_tile(bufK, dp, acc, i, grp); unpack(acc, dy);      // dy reused: dq
+      for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+      dl = grp_sum(dl);                                                    // delta = sum_key P dP = dO . O
+      if (grp == 0) rowc[64 * H + 64 * h + 16 * w + i] = dl;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dy[k] *= 0.125f;
+      for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);           // dS
+      f32x4 qa[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) qa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accum_tile_h<NCH>(bufK, dp, qa, i, grp, NCH * h);                    // dy reused: dq
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dy[4 * (NCH * h + c) + reg] = qa[c][reg] * qscale;
+    }
   }
   __syncthreads();   // Q, dO rows and delta of all tokens visible
   STAMP(10);
   // pass B (own keys): S, dP recomputed with the key on the lane; dV, dK
   float dk[16], dv[16];
-  {
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
     float sp[16], dp[16];
     {
-      float kf[16], vf[16];
-      load_rowT(kf, &bufK[(16 * w + i) * LD], LD, grp);
-      load_rowT(vf, &bufV[(16 * w + i) * LD], LD, grp);
-      zero4(acc); gemm_tile(bufQ, kf, acc, i, grp); unpack(acc, sp);      // S[q][key]
-      zero4(acc); gemm_tile(bufDO, vf, acc, i, grp); unpack(acc, dp);     // dP[q][key]
+      float kf[16], vf[16];   // only this head's column groups are loaded (and read)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ct = NCH * h + c;
+        float4 kv = *reinterpret_cast<const float4*>(&bufK[(16 * w + i) * LD + 16 * ct + 4 * grp]);
+        float4 vv = *reinterpret_cast<const float4*>(&bufV[(16 * w + i) * LD + 16 * ct + 4 * grp]);
+        kf[4 * ct] = kv.x; kf[4 * ct + 1] = kv.y; kf[4 * ct + 2] = kv.z; kf[4 * ct + 3] = kv.w;
+        vf[4 * ct] = vv.x; vf[4 * ct + 1] = vv.y; vf[4 * ct + 2] = vv.z; vf[4 * ct + 3] = vv.w;
+      }
+      zero4(acc); gemm_tile_h<NCH>(bufQ, kf, acc, i, grp, NCH * h); unpack(acc, sp);      // S[q][key]
+      zero4(acc); gemm_tile_h<NCH>(bufDO, vf, acc, i, grp, NCH * h); unpack(acc, dp);     // dP[q][key]
     }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-      float4 l4 = *reinterpret_cast<const float4*>(&rowc[16 * tt + 4 * grp]);
-      float4 d4 = *reinterpret_cast<const float4*>(&rowc[64 + 16 * tt + 4 * grp]);
+      float4 l4 = *reinterpret_cast<const float4*>(&rowc[64 * h + 16 * tt + 4 * grp]);
+      float4 d4 = *reinterpret_cast<const float4*>(&rowc[64 * H + 64 * h + 16 * tt + 4 * grp]);
       float pv;
       pv = __builtin_amdgcn_exp2f(sp[4 * tt + 0] * sc - l4.x); sp[4 * tt + 0] = pv; dp[4 * tt + 0] = pv * (dp[4 * tt + 0] - d4.x);
       pv = __builtin_amdgcn_exp2f(sp[4 * tt + 1] * sc - l4.y); sp[4 * tt + 1] = pv; dp[4 * tt + 1] = pv * (dp[4 * tt + 1] - d4.y);
       pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
       pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
     }
-    zero4(acc); accum_tile(bufDO, sp, acc, i, grp); unpack(acc, dv);    // dV = P^T dO
-    zero4(acc); accum_tile(bufQ, dp, acc, i, grp); unpack(acc, dk);     // dK = dS^T Q
+    f32x4 va[NCH], ka[NCH];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dk[k] *= 0.125f;
+    for (int c = 0; c < NCH; ++c) { va[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; ka[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    accum_tile_h<NCH>(bufDO, sp, va, i, grp, NCH * h);    // dV = P^T dO
+    accum_tile_h<NCH>(bufQ, dp, ka, i, grp, NCH * h);     // dK = dS^T Q
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        dv[4 * (NCH * h + c) + reg] = va[c][reg];
+        dk[4 * (NCH * h + c) + reg] = ka[c][reg] * qscale;
+      }
   }
   if (MODE == MODE_STORE) {
     store_rowT(dy, p.S_dqkv + srow_g * 3 * D, grp);
@@ -654,14 +721,14 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #undef PREFETCH
 #undef PUBLISH
 
-template <int MODE>
+template <int MODE, int H>
 __global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
     edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
     return;
   }
-  block_body<MODE>(p, lds, blockIdx.x / p.B, blockIdx.x % p.B, nullptr);
+  block_body<MODE, H>(p, lds, blockIdx.x / p.B, blockIdx.x % p.B, nullptr);
 }
 
 // Status "forward" chain (rule 'h -> u', /root/reference/src/decoder_transformer.py:167-168,175-176,
@@ -669,6 +736,7 @@ __global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
 // one image through all L blocks.  store_h: also write u_l into h_l (INIT rule 'h, u <- u',
 // /root/reference/pcx/predictive_coding/_vode.py:201).  Writes z = u_{L+1} Wout^T + bout to p.Z and
 // accumulates the clipped reconstruction error (:491-494) into p.mse.
+template <int H>
 __global__ __launch_bounds__(256, 1) void pc_chain_kernel(FusedP p, int store_h) {
   constexpr int D = 64, P = 48, LP = 52;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -693,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void pc_chain_kernel(FusedP p, int store_h)
   }
   for (int g = 0; g < p.L; ++g) {
     __syncthreads();   // LDS of the previous stage is no longer read
-    block_body<MODE_CHAIN>(p, lds, g, b, x);
+    block_body<MODE_CHAIN, H>(p, lds, g, b, x);
     if (store_h) store_rowT(x, const_cast<float*>(p.H1) + (long long)(g + 1) * nl + tok * D, grp);
   }
   __syncthreads();
@@ -722,26 +790,42 @@ __global__ __launch_bounds__(256, 1) void pc_chain_kernel(FusedP p, int store_h)
 }
 
 
-size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128) * sizeof(float); }
+size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128 * 4) * sizeof(float); }   // rowc sized for 4 heads
 
-int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st) {
+template <int H>
+static int launch_fused_h(const FusedP& p, int L, int store, hipStream_t st) {
   static bool attr = false;
   size_t sm = fused_block_lds_bytes();
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)pc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_chain_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     attr = true;
   }
-  if (store) hipLaunchKernelGGL(pc_block_fused_kernel<MODE_STORE>, dim3((L + 1) * p.B), dim3(256), sm, st, p);
-  else hipLaunchKernelGGL(pc_block_fused_kernel<MODE_INFER>, dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  if (L < 0) return 0;   // attribute set-up only
+  if (store == 2) hipLaunchKernelGGL(pc_chain_kernel<H>, dim3(p.B), dim3(256), sm, st, p, L /* store_h */);
+  else if (store) hipLaunchKernelGGL((pc_block_fused_kernel<MODE_STORE, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  else hipLaunchKernelGGL((pc_block_fused_kernel<MODE_INFER, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
 
+int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st) {
+  switch (p.H) {
+    case 1: return launch_fused_h<1>(p, L, store ? 1 : 0, st);
+    case 2: return launch_fused_h<2>(p, L, store ? 1 : 0, st);
+    case 4: return launch_fused_h<4>(p, L, store ? 1 : 0, st);
+  }
+  return -1;
+}
+
 int launch_chain(const FusedP& p, int store_h, hipStream_t st) {
-  size_t sm = fused_block_lds_bytes();
-  hipLaunchKernelGGL(pc_chain_kernel, dim3(p.B), dim3(256), sm, st, p, store_h);
-  return 0;
+  int rc = -1;
+  switch (p.H) {   // attributes first (a chain launch may be the first use of this head count)
+    case 1: rc = launch_fused_h<1>(p, -1, 0, st); if (!rc) rc = launch_fused_h<1>(p, store_h ? 1 : 0, 2, st); break;
+    case 2: rc = launch_fused_h<2>(p, -1, 0, st); if (!rc) rc = launch_fused_h<2>(p, store_h ? 1 : 0, 2, st); break;
+    case 4: rc = launch_fused_h<4>(p, -1, 0, st); if (!rc) rc = launch_fused_h<4>(p, store_h ? 1 : 0, 2, st); break;
+  }
+  return rc;
 }
 
 // ---- transposed weight copies: dst[c][r] = src[r][c] per group; up to 6 matrices per launch -----------

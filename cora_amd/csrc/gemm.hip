@@ -212,43 +212,90 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const in
   const float* tgt = p.tgt ? p.tgt + offC : nullptr;
   const float* hreg = p.hreg ? p.hreg + offC : nullptr;
   const float* aux = p.aux ? p.aux + offC : nullptr;
+#ifndef EPB
+#define EPB 16
+#endif
   double red = 0.0;
+  // Every operand the epilogue reads is fetched for EPB values at a time BEFORE the first store of that
+  // batch: the compiler must assume C aliases them, and a load -> wait -> store chain per element costs
+  // one exposed HBM latency per element.  Offsets are 32-bit (the launcher checks R * ldc < 2^31) to keep
+  // the batch's address registers from pushing the kernel below 4 waves per SIMD.
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = col0 + 32 * n + r;
-    const float bv = (bias && col < p.O) ? bias[col] : 0.f;
+    const bool colok = col < p.O;
+    const float bv = (bias && colok) ? bias[col] : 0.f;
+    const int rbase = row0 + 32 * w + 4 * hi;
+    const int obase = rbase * p.ldc + col;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = row0 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hi;
-      if (row < p.R && col < p.O) {
-        const long long idx = (long long)row * p.ldc + col;
-        float v = p.alpha * acc[n][i] + bv;
-        if (p.pos) v += p.pos[(long long)(row % p.posN) * p.O + col];
-        if (res1) v += res1[idx];
-        if (res2) v += res2[idx];
-        switch (p.mode) {
-          case OUT_STORE: C[idx] = v; break;
-          case OUT_ERR: {
-            float h = tgt[idx];
-            float e = h - v;
-            C[idx] = e;
-            red += (double)(0.5f * e * e + p.l1 * fabsf(h) + p.l2 * h * h);
-          } break;
-          case OUT_GELUGRAD: C[idx] = v * cora_gelu_grad(aux[idx]); break;
-          case OUT_GRAD: {
-            float own = tgt ? tgt[idx] : 0.f;
-            if (hreg) {
-              float h = hreg[idx];
-              float sg = (h > 0.f) ? 1.f : ((h < 0.f) ? -1.f : 0.f);
-              own += p.l1 * sg + 2.f * p.l2 * h;
-            }
-            float gv = p.alpha2 * (own - v);
-            C[idx] = gv;
-            red += (double)gv * (double)gv;
-          } break;
-          case OUT_ATOMIC: atomicAdd(&C[idx], v); break;
-        }
+    for (int half = 0; half < 16 / EPB; ++half) {
+#define EP_ROW(i) (rbase + ((i) & 3) + 8 * ((EPB / 4) * half + ((i) >> 2)))
+#define EP_OK(i) (colok && EP_ROW(i) < p.R)
+#define EP_IDX(i) (obase + (((i) & 3) + 8 * ((EPB / 4) * half + ((i) >> 2))) * p.ldc)
+#define EP_FETCH(dst, src)                                                                   \
+      _Pragma("unroll") for (int i = 0; i < EPB; ++i) dst[i] = EP_OK(i) ? (src)[EP_IDX(i)] : 0.f
+      float v[EPB], t0[EPB];
+#pragma unroll
+      for (int i = 0; i < EPB; ++i) v[i] = p.alpha * acc[n][EPB * half + i] + bv;
+      if (p.pos) {
+#pragma unroll
+        for (int i = 0; i < EPB; ++i) t0[i] = EP_OK(i) ? p.pos[(EP_ROW(i) % p.posN) * p.O + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
       }
+      if (res1) {
+        EP_FETCH(t0, res1);
+#pragma unroll
+        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
+      }
+      if (res2) {
+        EP_FETCH(t0, res2);
+#pragma unroll
+        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
+      }
+      switch (p.mode) {
+        case OUT_STORE:
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) C[EP_IDX(i)] = v[i];
+          break;
+        case OUT_ERR: {
+          EP_FETCH(t0, tgt);
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) {
+            const float h = t0[i], e = h - v[i];
+            C[EP_IDX(i)] = e;
+            red += (double)(0.5f * e * e + p.l1 * fabsf(h) + p.l2 * h * h);
+          }
+        } break;
+        case OUT_GELUGRAD: {
+          EP_FETCH(t0, aux);
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) C[EP_IDX(i)] = v[i] * cora_gelu_grad(t0[i]);
+        } break;
+        case OUT_GRAD: {
+          float hr[EPB];
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) { t0[i] = 0.f; hr[i] = 0.f; }
+          if (tgt) { EP_FETCH(t0, tgt); }
+          if (hreg) { EP_FETCH(hr, hreg); }
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) {
+            const float h = hr[i];
+            const float sg = (h > 0.f) ? 1.f : ((h < 0.f) ? -1.f : 0.f);
+            const float gv = p.alpha2 * (t0[i] + p.l1 * sg + 2.f * p.l2 * h - v[i]);
+            C[EP_IDX(i)] = gv;
+            red += (double)gv * (double)gv;
+          }
+        } break;
+        case OUT_ATOMIC:
+#pragma unroll
+          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) atomicAdd(&C[EP_IDX(i)], v[i]);
+          break;
+      }
+#undef EP_ROW
+#undef EP_OK
+#undef EP_IDX
+#undef EP_FETCH
     }
   }
   if (p.red) {
@@ -260,8 +307,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const in
   }
 }
 
+#ifndef GEMM_WAVES
+#define GEMM_WAVES 4
+#endif
 template <int BK, bool AKO, bool BKO, int BF16>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(256, GEMM_WAVES) void gemm_kernel(GemmP p) {
   gemm_body<BK, AKO, BKO, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 

@@ -32,6 +32,8 @@ CASES = {
     "tiny_1block_h1": ((3, 16, 16), 4, 32, 1, 1, 4, 3),
     "tiny_2block_h2": ((3, 16, 16), 4, 32, 2, 2, 4, 3),
     "cfg2_shape_B4": ((3, 32, 32), 4, 64, 1, 6, 4, 5),
+    "d64_h2_fused": ((3, 32, 32), 4, 64, 2, 3, 3, 4),      # fused kernel, head dim 32
+    "d64_h4_fused_12block": ((3, 32, 32), 4, 64, 4, 12, 2, 3),   # fused kernel, head dim 16 (a 12-block sweep point)
     "cfg3_shape_B2": ((3, 32, 32), 4, 128, 4, 12, 2, 3),
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
