@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--config", default="6block")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's batch_size)")
     ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--hidden-size", type=int, default=None, help="override the config (12-block sweep points)")
+    ap.add_argument("--num-heads", type=int, default=None)
+    ap.add_argument("--num-blocks", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = parity path (the headline number); bf16 = opt-in bf16-MFMA mode (per-op path)")
@@ -102,6 +105,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mc = ca.MODEL_CONFIGS[args.config]
+    over = {k: v for k, v in (("hidden_size", args.hidden_size), ("num_heads", args.num_heads),
+                              ("num_blocks", args.num_blocks)) if v is not None}
+    if over:
+        import dataclasses
+        mc = dataclasses.replace(mc, **over)
     tc = ca.transformer_config_from(mc)
     B = args.batch or mc.batch_size
     T = args.T or mc.inference_steps

@@ -728,7 +728,13 @@ __global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
     edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
     return;
   }
-  block_body<MODE, H>(p, lds, blockIdx.x / p.B, blockIdx.x % p.B, nullptr);
+  // XCD-aware order: the hardware deals workgroups round-robin over the 8 XCDs (id % 8), each with its
+  // own 4 MB L2.  Give XCD x the contiguous slice [x n/8, (x+1) n/8) of the (block, image) list so it
+  // touches the weights of at most two blocks instead of all L, and the L2 keeps the stash instead.
+  int j = (int)blockIdx.x;
+  const int n = p.L * p.B;
+  if ((n & 7) == 0) j = (j & 7) * (n >> 3) + (j >> 3);
+  block_body<MODE, H>(p, lds, j / p.B, j % p.B, nullptr);
 }
 
 // Status "forward" chain (rule 'h -> u', /root/reference/src/decoder_transformer.py:167-168,175-176,
