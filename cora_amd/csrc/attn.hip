@@ -302,6 +302,109 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// N <= 64 (the whole sequence is one chunk): both backward passes in one workgroup per (image, head).
+// Q, K, V and dO are staged once and shared by the query-owner pass (dQ, delta) and the key-owner pass
+// (dK, dV); delta = sum_key P dP crosses from one to the other through LDS, so neither O nor a delta
+// array in HBM is read.  Halves the HBM traffic of the two-kernel path, which is what bounds it here.
+template <int DH>
+struct AttnSmem4 {
+  static constexpr int LD = DH + 4;
+  float sK[CH * LD], sV[CH * LD], sQ[CH * LD], sdO[CH * LD];
+  float rowc[2 * CH];   // lse2 and delta of the 64 query rows
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+                                                             const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                             int N, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  AttnSmem4<DH>& sm = *reinterpret_cast<AttnSmem4<DH>*>(smem_raw);
+  constexpr int LD = DH + 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
+  const int img = blockIdx.z, h = blockIdx.y;
+  const int ld = 3 * D;
+  const float* base = qkv + (long long)img * N * ld;
+  const float scale = rsqrtf((float)DH);
+  const float sc = scale * CORA_LOG2E;
+  stage_rows<DH>(sm.sQ, base + h * DH, ld, 0, N);
+  stage_rows<DH>(sm.sK, base + D + h * DH, ld, 0, N);
+  stage_rows<DH>(sm.sV, base + 2 * D + h * DH, ld, 0, N);
+  stage_rows<DH>(sm.sdO, dO + (long long)img * N * D + h * DH, D, 0, N);
+  if (threadIdx.x < CH) sm.rowc[threadIdx.x] = ((int)threadIdx.x < N) ? lse2[((long long)img * N + threadIdx.x) * H + h] : 0.f;
+  __syncthreads();
+  const int row = 16 * w + c;                    // this lane's own row in both passes
+  float* drow = dqkv + ((long long)img * N + row) * ld + h * DH;
+  {  // ---- pass 1: own queries
+    float qf[DH / 4], dof[DH / 4];
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) { qf[s] = sm.sQ[row * LD + 4 * s + grp]; dof[s] = sm.sdO[row * LD + 4 * s + grp]; }
+    f32x4 S[4], dP[4];
+    score_tiles<DH>(S, sm.sK, qf, c, grp);
+    score_tiles<DH>(dP, sm.sV, dof, c, grp);
+    const float l2 = sm.rowc[row];
+    float dl = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int key = 16 * tt + 4 * grp + reg;
+        const float pv = (key < N && row < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - l2) : 0.f;
+        S[tt][reg] = pv;
+        dl += pv * dP[tt][reg];
+      }
+    dl = grp_sum(dl);                            // delta = sum_key P dP  (= dO . O)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) S[tt][reg] *= dP[tt][reg] - dl;   // dS
+    f32x4 acc[NT16(DH)];
+#pragma unroll
+    for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accum_tiles<DH>(acc, sm.sK, S, c, grp);      // dQ^T += K^T dS^T
+    if (row < N) {
+#pragma unroll
+      for (int ct = 0; ct < NT16(DH); ++ct)
+        if (16 * ct + 4 * grp < DH)
+          *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) =
+              make_float4(acc[ct][0] * scale, acc[ct][1] * scale, acc[ct][2] * scale, acc[ct][3] * scale);
+    }
+    if (grp == 0) sm.rowc[CH + row] = dl;
+  }
+  __syncthreads();
+  {  // ---- pass 2: own keys
+    float kf[DH / 4], vf[DH / 4];
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) { kf[s] = sm.sK[row * LD + 4 * s + grp]; vf[s] = sm.sV[row * LD + 4 * s + grp]; }
+    f32x4 S[4], dP[4];
+    score_tiles<DH>(S, sm.sQ, kf, c, grp);       // S[q][key]
+    score_tiles<DH>(dP, sm.sdO, vf, c, grp);     // dP[q][key] = dO[q] . V[key]
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ql = 16 * tt + 4 * grp + reg;
+        const float pv = (ql < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - sm.rowc[ql]) : 0.f;
+        S[tt][reg] = pv;                                          // P
+        dP[tt][reg] = pv * (dP[tt][reg] - sm.rowc[CH + ql]);      // dS
+      }
+    f32x4 dk[NT16(DH)], dv[NT16(DH)];
+#pragma unroll
+    for (int ct = 0; ct < NT16(DH); ++ct) { dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    accum_tiles<DH>(dv, sm.sdO, S, c, grp);      // dV^T += dO^T P
+    accum_tiles<DH>(dk, sm.sQ, dP, c, grp);      // dK^T += Q^T dS
+    if (row < N) {
+#pragma unroll
+      for (int ct = 0; ct < NT16(DH); ++ct)
+        if (16 * ct + 4 * grp < DH) {
+          *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) =
+              make_float4(dk[ct][0] * scale, dk[ct][1] * scale, dk[ct][2] * scale, dk[ct][3] * scale);
+          *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = make_float4(dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int DH>
 static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
   size_t sm = sizeof(AttnSmem<DH>);
@@ -317,6 +420,16 @@ static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int
 template <int DH>
 static int run_bwd(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
                    float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+  if (N <= CH && DH <= 64) {   // one chunk: fused backward
+    size_t sm4 = sizeof(AttnSmem4<DH>);
+    static bool attr4 = false;
+    if (!attr4 && sm4 > 48 * 1024) {
+      if (hipFuncSetAttribute((const void*)attn_bwd_small_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4) != hipSuccess) return -1;
+      attr4 = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_small_kernel<DH>), dim3(1, H, nimg), dim3(256), sm4, st, qkv, lse2, dO, dqkv, N, H, D);
+    return 0;
+  }
   size_t sm = sizeof(AttnSmem<DH>);
   static bool attr_set = false;
   if (!attr_set && sm > 48 * 1024) {
