@@ -603,6 +603,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     }
   }
   STAMP(8);
+  float pT[H == 1 ? 16 : 1], dsT[H == 1 ? 16 : 1];
   {  // dO = dy Wo ; from here on r + dy is all that is needed of either
     float dof[16];
     PUBLISH(0, t); PREFETCH(WqkvT, 3 * D);          // tile 20: Wo^T; -> tile 21 (waits in registers through the attention backward)
@@ -618,7 +619,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     // attention backward, pass A (own queries): dP, delta, dS, dQ -- head by head
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      float pf[16], dp[16];
+      float pf_[16], dp_[16];
+      float* pf = (H == 1) ? pT : pf_;     // one head: P and dS outlive the pass (handed to pass B through LDS)
+      float* dp = (H == 1) ? dsT : dp_;
       load_rowT(pf, st_p + 64 * h, D, grp);
       zero4(acc); gemm_tile_h<NCH>(bufV, dof, acc, i, grp, NCH * h); unpack(acc, dp);   // dP[key][q] = V[key] . dO[q]
       float dl = 0.f;
@@ -638,12 +641,32 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
         for (int reg = 0; reg < 4; ++reg) dy[4 * (NCH * h + c) + reg] = qa[c][reg] * qscale;
     }
   }
-  __syncthreads();   // Q, dO rows and delta of all tokens visible
+  __syncthreads();   // Q, dO rows and delta of all tokens visible; K and V no longer read (one head)
   STAMP(10);
-  // pass B (own keys): S, dP recomputed with the key on the lane; dV, dK
   float dk[16], dv[16];
+  if (H == 1) {
+    // pass B (own keys), one head: P and dS cross from the query owners to the key owners through the
+    // K / V tiles, which are dead now -- rows = queries as written, each lane gathers its key's column.
+    // 32 LDS reads instead of 128 MFMAs + 16 exp2 per wave to recompute S and dP.
+    store_rowT(pT, &bufK[(16 * w + i) * LD], grp);
+    store_rowT(dsT, &bufV[(16 * w + i) * LD], grp);
+    __syncthreads();
+    float sp[16], dp[16];
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        sp[4 * tt + reg] = bufK[(16 * tt + 4 * grp + reg) * LD + 16 * w + i];
+        dp[4 * tt + reg] = bufV[(16 * tt + 4 * grp + reg) * LD + 16 * w + i];
+      }
+    zero4(acc); accum_tile(bufDO, sp, acc, i, grp); unpack(acc, dv);    // dV = P^T dO
+    zero4(acc); accum_tile(bufQ, dp, acc, i, grp); unpack(acc, dk);     // dK = dS^T Q
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dk[k] *= qscale;
+  }
+  // pass B (own keys), several heads: S, dP recomputed with the key on the lane; dV, dK
+#pragma unroll
+  for (int h = 0; h < (H == 1 ? 0 : H); ++h) {
     float sp[16], dp[16];
     {
       float kf[16], vf[16];   // only this head's column groups are loaded (and read)
