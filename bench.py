@@ -250,6 +250,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(mc, tc, B, T)
         else:
             result["cpu_baseline"] = None
+        if timing_build:    # not a product number: the library was swapped for a diagnostic build
+            result["diagnostic_library"] = os.environ["CORA_HIP_LIB"]
         print(json.dumps(result))
     model.close()
     if dist is not None:
