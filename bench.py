@@ -139,7 +139,7 @@ def main():
         if dp is None:
             _lib.check(lib.cora_step(ctx, xptr, 1, T, eptr, eta_w, C.byref(out)), ctx)
         else:
-            _lib.check(lib.cora_infer(ctx, xptr, 1, T, eptr, C.byref(out)), ctx)
+            _lib.check(lib.cora_infer(ctx, xptr, 1, T, eptr, None), ctx)      # in flight; cora_wgrad ends it
             _lib.check(lib.cora_wgrad(ctx, C.byref(out)), ctx)
             w = dp.allreduce()
             _lib.check(lib.cora_apply_wgrad(ctx, eta_w, C.c_float(1.0 / (B * w)), C.byref(out)), ctx)

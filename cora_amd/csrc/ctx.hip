@@ -83,6 +83,7 @@ struct cora_ctx {
 
   std::map<int, hipGraphExec_t> graphs;
   bool learn_warm = false;
+  bool infer_pending = false;   // cora_infer(out = NULL) launched, not yet synchronised (cora_wgrad ends it)
   hipGraphExec_t learn_graph = nullptr;
   // data-parallel path: the two halves around the all-reduce, captured separately
   hipGraphExec_t wgrad_graph = nullptr, apply_graph = nullptr;
@@ -903,10 +904,20 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h) FAIL(-1, "eta_h is NULL");
   HCHECK(hipSetDevice(c->device));
+  // out == NULL (graph mode): nothing is read back here, so the call returns with the loop still in
+  // flight and cora_wgrad, which must follow, ends it -- one host synchronisation less per batch on
+  // the data-parallel path.  eta_h then goes through the ctx's pinned staging buffer.
+  const bool deferred = !out && c->use_graph && !c->prof;
+  if (c->infer_pending) { HCHECK(hipStreamSynchronize(c->st)); c->infer_pending = false; }
   int rc = upload_x(c, x, x_on_device);
   if (rc) return rc;
-  HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
-  HCHECK(hipStreamSynchronize(c->st));   // eta_h / x are caller-owned: copied before we return
+  if (deferred) {
+    memcpy(c->host_in, eta_h, sizeof(float) * T);
+    HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  } else {
+    HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+    HCHECK(hipStreamSynchronize(c->st));   // eta_h / x are caller-owned: copied before we return
+  }
   c->last_T = T;
   if (!c->use_graph || c->prof) {
     HCHECK(hipEventRecord(c->ev0, c->st));
@@ -920,6 +931,7 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
     HCHECK(hipGraphLaunch(gi, c->st));
     HCHECK(hipEventRecord(c->ev1, c->st));
   }
+  if (deferred) { c->infer_pending = true; return 0; }
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {
     float ms = 0.f;
@@ -1072,6 +1084,30 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
     HCHECK(hipGraphInstantiate(&c->wgrad_graph, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
+  }
+  if (c->infer_pending) {
+    // ends a cora_infer(out = NULL): both phases behind ONE synchronisation, scalars through pinned memory
+    c->infer_pending = false;
+    if (graphed) HCHECK(hipGraphLaunch(c->wgrad_graph, c->st));
+    else if ((rc = enqueue_wgrad(c))) return rc;
+    HCHECK(hipEventRecord(c->ev2, c->st));
+    const int T = c->last_T;
+    double* ho = c->host_out;
+    const size_t nslot = (size_t)(L + 3) * 8;
+    if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+    else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+    HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)slot * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+    HCHECK(hipStreamSynchronize(c->st));
+    if (out) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
+      hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
+      double eh = 0.0, ew = 0.0;
+      for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+      for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
+      out->final_h_energy = eh; out->final_w_energy = ew;
+    }
+    return 0;
   }
   HCHECK(hipEventRecord(c->ev0, c->st));
   if (graphed) HCHECK(hipGraphLaunch(c->wgrad_graph, c->st));

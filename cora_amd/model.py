@@ -482,7 +482,7 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
         if model._dp.exact_clip:
             model._dp.infer_exact(model, ctx, x, T, eta_h, out)
         else:
-            _lib.check(lib.cora_infer(ctx, _fptr(x), 0, T, _fptr(eta_h), C.byref(out)), ctx)
+            _lib.check(lib.cora_infer(ctx, _fptr(x), 0, T, _fptr(eta_h), None), ctx)   # ended by cora_wgrad
         _lib.check(lib.cora_wgrad(ctx, C.byref(out)), ctx)
         world = model._dp.allreduce()
         _lib.check(lib.cora_apply_wgrad(ctx, C.c_float(eta_w), C.c_float(1.0 / (B * world)), C.byref(out)), ctx)

@@ -123,7 +123,9 @@ int cora_step(cora_ctx* ctx, const float* x, int x_on_device, int T, const float
 
 /* The same step split at the data-parallel exchange point: cora_infer + cora_wgrad leave the
  * LOCAL sum of dE/dW in the wgrad buffer; the host all-reduces that buffer (RCCL) and then calls
- * cora_apply_wgrad with scale_by = 1/B_total. */
+ * cora_apply_wgrad with scale_by = 1/B_total.  cora_infer with out == NULL returns while the loop is
+ * still in flight (x, if a device pointer, must stay valid); the cora_wgrad that follows ends both
+ * with one synchronisation and reports final_h_energy / infer_ms as well. */
 int cora_infer(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h,
                cora_step_out* out);
 int cora_wgrad(cora_ctx* ctx, cora_step_out* out);

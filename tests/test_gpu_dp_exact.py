@@ -96,3 +96,27 @@ def test_two_ranks_exact_clip_match_one_rank(name):
     loc = _run_sharded(name, exact=False)
     got = np.concatenate([loc[0][1][L + 1], loc[1][1][L + 1]], axis=0)
     assert np.abs(got - h_ref[L + 1]).max() / np.abs(h_ref[L + 1]).max() > 1e-4
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_split_step_single_rank_matches_fused_step(name):
+    """World size 1, no process group: cora_infer(out=NULL) + cora_wgrad + identity all-reduce +
+    cora_apply_wgrad (the data-parallel call sequence, inference loop left in flight until the weight
+    gradients are enqueued) against the one-call cora_step, two batches each so the graphed path runs."""
+    import cora_amd as ca
+    from cora_amd.dist import DataParallel
+    case, T = _case(name)
+    res = []
+    for split in (False, True):
+        model, ow, oh = build_model(case)
+        if split:
+            DataParallel(model, case["x"].shape[0])
+        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(3)]
+        res.append((outs[-1], [model.vodes[l].h.get() for l in range(len(case["h"]))], model.get_weights()))
+        model.close()
+    (a, ha, wa), (b, hb, wb) = res
+    assert a[0] == pytest.approx(b[0], rel=1e-5) and a[1] == pytest.approx(b[1], rel=1e-5) and a[4] == pytest.approx(b[4], rel=1e-5)
+    for x, y in zip(ha, hb):
+        assert np.abs(x - y).max() <= 1e-4 * np.abs(x).max()
+    for k in wa:
+        assert np.abs(wa[k] - wb[k]).max() <= 1e-4 * max(np.abs(wa[k]).max(), 1e-3), k
