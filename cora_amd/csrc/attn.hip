@@ -408,10 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
 template <int DH>
 static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
   size_t sm = sizeof(AttnSmem<DH>);
-  static bool attr_set = false;
-  if (!attr_set && sm > 48 * 1024) {
+  static bool attr_set[64] = {};
+  if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    attr_set = true;
   }
   dim3 grid((N + 63) / 64, H, nimg);
   hipLaunchKernelGGL((attn_fwd_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, N, H, D);
@@ -422,20 +421,18 @@ static int run_bwd(const float* qkv, const float* O, const float* lse2, const fl
                    float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
   if (N <= CH && DH <= 64) {   // one chunk: fused backward
     size_t sm4 = sizeof(AttnSmem4<DH>);
-    static bool attr4 = false;
-    if (!attr4 && sm4 > 48 * 1024) {
+    static bool attr4[64] = {};
+    if (sm4 > 48 * 1024 && first_use_on_device(attr4)) {
       if (hipFuncSetAttribute((const void*)attn_bwd_small_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4) != hipSuccess) return -1;
-      attr4 = true;
     }
     hipLaunchKernelGGL((attn_bwd_small_kernel<DH>), dim3(1, H, nimg), dim3(256), sm4, st, qkv, lse2, dO, dqkv, N, H, D);
     return 0;
   }
   size_t sm = sizeof(AttnSmem<DH>);
-  static bool attr_set = false;
-  if (!attr_set && sm > 48 * 1024) {
+  static bool attr_set[64] = {};
+  if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    attr_set = true;
   }
   dim3 grid((N + 63) / 64, H, nimg);
   hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, dO, delta, dqkv, N, H, D);

@@ -52,6 +52,16 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
   return r;
 }
 
+// Kernel attributes (dynamic LDS above 48 KB) are per device: true the first time `flags` is asked on
+// the current device, so a process that drives several GPUs sets them on each.
+inline bool first_use_on_device(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (flags[dev]) return false;
+  flags[dev] = true;
+  return true;
+}
+
 // ---- GEMM parameter block ----------------------------------------------------------------------
 enum GemmOut {
   OUT_STORE = 0,     // C = v

@@ -823,13 +823,12 @@ size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128 * 4) * sizeof(fl
 
 template <int H>
 static int launch_fused_h(const FusedP& p, int L, int store, hipStream_t st) {
-  static bool attr = false;
+  static bool attr[64] = {};
   size_t sm = fused_block_lds_bytes();
-  if (!attr) {
+  if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_chain_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
-    attr = true;
   }
   if (L < 0) return 0;   // attribute set-up only
   if (store == 2) hipLaunchKernelGGL(pc_chain_kernel<H>, dim3(p.B), dim3(256), sm, st, p, L /* store_h */);
