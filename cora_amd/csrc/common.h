@@ -30,6 +30,17 @@ __device__ __forceinline__ float cora_gelu_grad(float a) {
   return __builtin_fmaf(a * s_ * r, du, s_);
 }
 
+// both at once (the inference kernel keeps gelu'(a) for its backward instead of a: one exp2 / rcp per value)
+__device__ __forceinline__ void cora_gelu_both(float a, float& g, float& gp) {
+  float a2 = a * a;
+  float e = __builtin_amdgcn_exp2f(a * __builtin_fmaf(CORA_GELU_K1, a2, CORA_GELU_K0));
+  float r = __builtin_amdgcn_rcpf(1.0f + e);      // 1 - s
+  float s_ = 1.0f - r;
+  float du = __builtin_fmaf(0.2140644488f, a2, 1.5957691216f);
+  g = __builtin_fmaf(-a, r, a);
+  gp = __builtin_fmaf(a * s_ * r, du, s_);
+}
+
 // ---- wave (64 lanes) and block reductions ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -409,7 +409,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], y[16];
-  // MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
+  // gelu'(a) of the MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
   // the backward; the STORE pass writes it to HBM anyway (weight-gradient GEMM operand) and reloads it.
   float a_keep[MODE == MODE_INFER ? 64 : 1];
   if (MODE == MODE_CHAIN) {
@@ -515,12 +515,13 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
         for (int k = 0; k < 16; ++k) am[k] += b1[k];
       }
       if (MODE == MODE_STORE) store_rowT(am, st_a + 64 * mt, grp);
-      if (MODE == MODE_INFER) {
+      if (MODE == MODE_INFER) {   // keep gelu'(a) for the backward: it shares the exp2 / rcp with gelu(a)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a_keep[16 * mt + k] = am[k];
+        for (int k = 0; k < 16; ++k) cora_gelu_both(am[k], am[k], a_keep[16 * mt + k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
       }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
       PUBLISH(1, t);                                        // tile 5+2mt: W2[:, mt]
       if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D);      // -> tile 6+2mt
       else if (MODE != MODE_CHAIN) PREFETCH(W2T, D);        // -> tile 12: W2^T[0]
@@ -577,17 +578,19 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       PUBLISH(0, t);                                        // tile 12+2mt: W2^T[mt]
       if (mt < 2) SUB(3 + 6 * mt);
       PREFETCH(W1T + mt * 64, M);                           // -> tile 13+2mt: W1^T[:, mt]
-      float am[16], dg[16];
+      float am[16], dg[16];     // am: gelu'(a) (inference kernel) or a (STORE pass)
       if (MODE == MODE_INFER) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] = a_keep[16 * mt + k];
       } else {
         load_rowT(am, st_a + 64 * mt, M, grp);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) am[k] = cora_gelu_grad(am[k]);
       }
       if (mt < 2) SUB(4 + 6 * mt);
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) dg[k] *= cora_gelu_grad(am[k]);
+      for (int k = 0; k < 16; ++k) dg[k] *= am[k];
       if (MODE == MODE_STORE) {
         store_rowT(dg, p.S_da + srow_g * M + 64 * mt, grp);
         colsum_store<4>(dg, cpart + CP_B1 + 64 * mt, i, grp);
