@@ -41,6 +41,20 @@ __device__ __forceinline__ void cora_gelu_both(float a, float& g, float& gp) {
   gp = __builtin_fmaf(a * s_ * r, du, s_);
 }
 
+// two values per call on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32); exp2 / rcp stay scalar
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cora_gelu_both2(f32x2 a, f32x2& g, f32x2& gp) {
+  const f32x2 a2 = a * a;
+  const f32x2 u = a * (a2 * CORA_GELU_K1 + CORA_GELU_K0);
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u.x));
+  r.y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u.y));
+  const f32x2 s_ = 1.0f - r;
+  const f32x2 du = a2 * 0.2140644488f + 1.5957691216f;
+  g = a - a * r;
+  gp = (a * s_ * r) * du + s_;
+}
+
 // ---- wave (64 lanes) and block reductions ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

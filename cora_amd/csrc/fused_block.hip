@@ -517,7 +517,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (MODE == MODE_STORE) store_rowT(am, st_a + 64 * mt, grp);
       if (MODE == MODE_INFER) {   // keep gelu'(a) for the backward: it shares the exp2 / rcp with gelu(a)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) cora_gelu_both(am[k], am[k], a_keep[16 * mt + k]);
+        for (int k = 0; k < 16; k += 2) {
+          f32x2 g2, gp2;
+          cora_gelu_both2((f32x2){am[k], am[k + 1]}, g2, gp2);
+          am[k] = g2.x; am[k + 1] = g2.y;
+          a_keep[16 * mt + k] = gp2.x; a_keep[16 * mt + k + 1] = gp2.y;
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
