@@ -367,10 +367,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
                                  : ln1g + 4 * (tid - 112);
     *reinterpret_cast<float4*>(pb + 4 * tid) = *reinterpret_cast<const float4*>(src);   // visible after the first tile barrier
   }
-  // the next vode's tile (the target of this block's prediction) is first needed after the MLP, where
-  // no register can hold it: touch its 16 KB now so that load finds it in L2 instead of HBM
-  float touch = 0.f;
-  if (MODE != MODE_CHAIN) touch = (p.H1 + (long long)(g + 1) * nl + (long long)b * 64 * D)[16 * tid];
 
   // ---- weight tile pipeline: global -> registers (prefetched one tile ahead) -> LDS (double buffered)
   // 24 tiles per block, tile k goes to LDS buffer k&1.  While tile k is computed, tile k+1 is in
@@ -427,7 +423,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       ln_rowT(x, gm, bt, xh, xin);
       if (MODE == MODE_STORE) store_rowT(xin, p.S_xn1 + srow_g * D, grp);
     }
-    asm volatile("" :: "v"(touch));   // keeps the touch load alive; x (issued later) has arrived by now
     STAMP(1);
     float qf[16];
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
@@ -489,6 +484,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     for (int k = 0; k < 16; ++k) y[k] += x[k];
     if (MODE != MODE_CHAIN) store_rowT(y, st_y, grp);
   }
+  float hn[16];
   {
     float zn[16];
     {
@@ -499,6 +495,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (MODE == MODE_STORE) store_rowT(zn, p.S_xn2 + srow_g * D, grp);
     }
     STAMP(4);
+    // the next vode's rows (target of this block's prediction): fetched here so the HBM latency runs
+    // under the MLP instead of in front of the error
+    if (MODE != MODE_CHAIN) load_rowT(hn, hnext, D, grp);
     // a_mt = LN2(y) W1[mt]^T + b1 ; z += gelu(a_mt) W2[:, mt]^T   (row tile of W1, K-chunk of W2, interleaved)
     f32x4 zacc[4];
     zero4(zacc);
@@ -536,16 +535,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     float z[16], b2[16];
     unpack(zacc, z);
     load_rowT(b2, pb + PB_B2, D, grp);
-    if (MODE == MODE_INFER) {
-      // x and y were dropped across the MLP loop to make room for a_keep: fetch them again (y from
-      // the stash it was parked in; the pointers are laundered so the compiler cannot keep the
-      // stored values live in registers instead)
-      const float* xp_ = xrow;
-      const float* yp_ = st_y;
-      asm volatile("" : "+v"(xp_), "+v"(yp_));
-      load_rowT(x, xp_, D, grp);
-      load_rowT(y, yp_, D, grp);
-    }
     if (MODE == MODE_CHAIN) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) xio[k] = x[k] + y[k] + z[k] + b2[k];
@@ -556,8 +545,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   }
   float r[16];
   {
-    float hn[16];
-    load_rowT(hn, hnext, D, grp);
     float en = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
