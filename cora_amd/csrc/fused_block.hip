@@ -340,11 +340,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
   float* cpart = (MODE == MODE_STORE) ? p.colpart + (((long long)g * p.B + b) * 4 + w) * COLPART : nullptr;
   // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
-  // in the forward and only needed again in the backward (q, P, y, the MLP pre-activation a) are
+  // in the forward and only needed again in the backward (q, P; in the STORE pass also a) are
   // parked in an L2-resident stash instead of registers and reloaded at their point of use.
-  float* st_q = p.S_stash + srow_g * ((2 + H) * D);
+  float* st_q = p.S_stash + srow_g * ((1 + H) * D);
   float* st_p = st_q + D;                // H x 64: one row of P per head
-  float* st_y = st_q + (1 + H) * D;
   float* st_a = p.S_a + srow_g * M;
 
   const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
@@ -482,7 +481,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
-    if (MODE != MODE_CHAIN) store_rowT(y, st_y, grp);
   }
   float hn[16];
   {
@@ -541,14 +539,14 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       return;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) y[k] = x[k] + y[k] + z[k] + b2[k];     // y now holds u
+    for (int k = 0; k < 16; ++k) x[k] = x[k] + y[k] + z[k] + b2[k];     // x now holds u; y stays for LN2's backward
   }
   float r[16];
   {
     float en = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      r[k] = hn[k] - y[k];
+      r[k] = hn[k] - x[k];
       en += 0.5f * r[k] * r[k] + p.l1 * fabsf(hn[k]) + p.l2 * hn[k] * hn[k];
     }
     store_rowT(r, p.E2 + (long long)g * nl + rowoff, grp);
@@ -595,10 +593,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (mt < 2) SUB(7 + 6 * mt);
     }
     STAMP(7);
-    // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from the stashed y
-    float dzn[16], gm[16], bt[16], xh[17], yv[16], tmp[16];
+    // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from y (still in registers)
+    float dzn[16], gm[16], bt[16], xh[17], tmp[16];
+    const float* yv = y;
     unpack(dacc, dzn);
-    load_rowT(yv, st_y, D, grp);
     load_rowT(gm, pb + PB_LN2G, D, grp);
 #pragma unroll
     for (int k = 0; k < 16; ++k) bt[k] = 0.f;
