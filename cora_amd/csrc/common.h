@@ -210,7 +210,7 @@ struct FusedP {
   long long oWp, obp, oWout, obout, tWp, tWout;
   // MODE_STORE: tensors the weight-gradient GEMMs read ([L*B*N, cols], same layout as the general path)
   float *S_xn1, *S_att, *S_xn2, *S_a, *S_da, *S_dy, *S_dqkv;
-  float* S_stash;   // [L*B*N, (1+H) D]: q | P (one 64-key row per head) parked between forward and backward
+  float* S_stash;   // [L*B*N, H D]: P (one 64-key row per head) parked between forward and backward
   float* dW;        // MODE_STORE: bias / LayerNorm-parameter gradients land here (null otherwise)
   float* colpart;   // MODE_STORE: per-wave column sums of the block workgroups (fused_colpart_floats)
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error

@@ -662,7 +662,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->da, rows * M); DA(c->dzn, rows * D); DA(c->dy, rows * D); DA(c->dO, rows * D); DA(c->delta, rows * c->H);
   DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
   DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
-  if (c->fused) DA(c->stash, rows * (1 + c->H) * D);
+  if (c->fused) DA(c->stash, rows * c->H * D);
   DA(c->gscale, 64); DA(c->eta_dev, c->Tmax + 1);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;

@@ -340,10 +340,9 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;   // row in the [L*B*N, .] scratch tensors
   float* cpart = (MODE == MODE_STORE) ? p.colpart + (((long long)g * p.B + b) * 4 + w) * COLPART : nullptr;
   // Register diet (the kernel must fit 256 VGPRs for two waves per SIMD): tensors that are produced
-  // in the forward and only needed again in the backward (q, P; in the STORE pass also a) are
+  // in the forward and only needed again in the backward (P; in the STORE pass also a) are
   // parked in an L2-resident stash instead of registers and reloaded at their point of use.
-  float* st_q = p.S_stash + srow_g * ((1 + H) * D);
-  float* st_p = st_q + D;                // H x 64: one row of P per head
+  float* st_p = p.S_stash + srow_g * (H * D);   // H x 64: one row of P per head
   float* st_a = p.S_a + srow_g * M;
 
   const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
@@ -404,6 +403,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], y[16];
+  float qkeep[MODE == MODE_CHAIN ? 1 : 16];   // q of the forward, kept for the attention backward
   // gelu'(a) of the MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
   // the backward; the STORE pass writes it to HBM anyway (weight-gradient GEMM operand) and reloads it.
   float a_keep[MODE == MODE_INFER ? 64 : 1];
@@ -429,7 +429,10 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
      
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, qf);
      
-      if (MODE != MODE_CHAIN) store_rowT(qf, st_q, grp);
+      if (MODE != MODE_CHAIN) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) qkeep[k] = qf[k];
+      }
       float kf[16];
      
       PUBLISH(1, t); PREFETCH(Wqkv + 128 * D, D);   // -> tile 2: Wv
@@ -622,9 +625,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     for (int k = 0; k < 16; ++k) r[k] += dy[k];
     __syncthreads();   // every wave is done with the weight buffers: reuse them for Q and dO
     store_rowT(dof, &bufDO[(16 * w + i) * LD], grp);
-    float qf[16];
-    load_rowT(qf, st_q, D, grp);
-    store_rowT(qf, &bufQ[(16 * w + i) * LD], grp);
+    store_rowT(qkeep, &bufQ[(16 * w + i) * LD], grp);
     STAMP(9);
     // attention backward, pass A (own queries): dP, delta, dS, dQ -- head by head
 #pragma unroll
