@@ -619,6 +619,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   float pT[H == 1 ? 16 : 1], dsT[H == 1 ? 16 : 1];
   {  // dO = dy Wo ; from here on r + dy is all that is needed of either
     float dof[16];
+    if (H == 1) load_rowT(pT, st_p, D, grp);        // P back from the stash under the Wo^T tile (the MLP's registers are free again)
     PUBLISH(0, t); PREFETCH(WqkvT, 3 * D);          // tile 20: Wo^T; -> tile 21 (waits in registers through the attention backward)
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
 #pragma unroll
@@ -633,7 +634,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       float pf_[16], dp_[16];
       float* pf = (H == 1) ? pT : pf_;     // one head: P and dS outlive the pass (handed to pass B through LDS)
       float* dp = (H == 1) ? dsT : dp_;
-      load_rowT(pf, st_p + 64 * h, D, grp);
+      if (H > 1) load_rowT(pf, st_p + 64 * h, D, grp);
       zero4(acc); gemm_tile_h<NCH>(bufV, dof, acc, i, grp, NCH * h); unpack(acc, dp);   // dP[key][q] = V[key] . dO[q]
       float dl = 0.f;
 #pragma unroll
