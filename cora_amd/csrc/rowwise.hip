@@ -244,14 +244,12 @@ __device__ void vode_multipliers(const UpdateP& p, float* mult) {
 
 __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   __shared__ float mult_sh[66];
-  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
-  __syncthreads();
-  const float eta = p.eta[p.t];
   const long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   constexpr int NS = 2;   // independent float4 triples in flight per thread
-  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += NS * stride) {
-    float4 g[NS], m[NS], h[NS];
+  float4 g[NS], m[NS], h[NS];
+  long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto fetch = [&]() {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const long long e = 4 * (i0 + u * stride);
@@ -261,6 +259,14 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
         h[u] = *reinterpret_cast<const float4*>(p.h + e);
       }
     }
+  };
+  // the first (usually only) batch of loads is issued BEFORE the per-leaf multipliers are worked out by
+  // thread 0: they do not depend on them, and the block's start-up then costs one memory latency, not two
+  fetch();
+  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
+  __syncthreads();
+  const float eta = p.eta[p.t];
+  while (i0 < n4) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       if (i0 + u * stride >= n4) break;
@@ -273,6 +279,8 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
       *reinterpret_cast<float4*>(p.m + e) = m[u];
       *reinterpret_cast<float4*>(p.h + e) = h[u];
     }
+    i0 += NS * stride;
+    if (i0 < n4) fetch();
   }
 }
 __global__ __launch_bounds__(256) void sens_update_kernel(UpdateP p, float* __restrict__ hs, float* __restrict__ ms,
