@@ -976,7 +976,7 @@ int enqueue_wgrad(cora_ctx* c) {
     const long long sD = (long long)R * D, sM = (long long)R * M, s3 = (long long)R * 3 * D;
     GemmMulti m; memset(&m, 0, sizeof m);
     m.n = 6;
-    m.p[0] = wgrad_problem(c, L, r, D, sD, c->a, M, sM, c->dW + c->oW2, (long long)D * M, 1);        // dW2 = -r^T gelu(a)
+    m.p[0] = wgrad_problem(c, L, r, D, sD, c->a, M, sM, c->dW + c->oW2, (long long)D * M, 0);        // dW2 = -r^T gelu(a); the STORE pass left gelu(a) in c->a
     m.p[1] = wgrad_problem(c, L, c->da, M, sM, c->xn2, D, sD, c->dW + c->oW1, (long long)M * D, 0);   // dW1 = -da^T LN2(y)
     m.p[2] = wgrad_problem(c, L, c->dqkv, 3 * D, s3, c->xn1, D, sD, c->dW + c->oWqkv, 3LL * D * D, 0);
     m.p[3] = wgrad_problem(c, L, c->dy, D, sD, c->att, D, sD, c->dW + c->oWo, (long long)D * D, 0);   // dWo = -dy^T att

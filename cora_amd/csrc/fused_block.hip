@@ -514,7 +514,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] += b1[k];
       }
-      if (MODE == MODE_STORE) store_rowT(am, st_a + 64 * mt, grp);
       if (MODE == MODE_INFER) {   // keep gelu'(a) for the backward: it shares the exp2 / rcp with gelu(a)
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
@@ -523,6 +522,18 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
           am[k] = g2.x; am[k + 1] = g2.y;
           a_keep[16 * mt + k] = gp2.x; a_keep[16 * mt + k + 1] = gp2.y;
         }
+      } else if (MODE == MODE_STORE) {
+        // the weight-gradient GEMM wants gelu(a) (S_a); gelu'(a) waits in the S_da slot that da overwrites in the backward
+        float gpv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          f32x2 g2, gp2;
+          cora_gelu_both2((f32x2){am[k], am[k + 1]}, g2, gp2);
+          am[k] = g2.x; am[k + 1] = g2.y;
+          gpv[k] = gp2.x; gpv[k + 1] = gp2.y;
+        }
+        store_rowT(am, st_a + 64 * mt, grp);
+        store_rowT(gpv, p.S_da + srow_g * M + 64 * mt, grp);
       } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
@@ -571,14 +582,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       PUBLISH(0, t);                                        // tile 12+2mt: W2^T[mt]
       if (mt < 2) SUB(3 + 6 * mt);
       PREFETCH(W1T + mt * 64, M);                           // -> tile 13+2mt: W1^T[:, mt]
-      float am[16], dg[16];     // am: gelu'(a) (inference kernel) or a (STORE pass)
+      float am[16], dg[16];     // am: gelu'(a)
       if (MODE == MODE_INFER) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] = a_keep[16 * mt + k];
       } else {
-        load_rowT(am, st_a + 64 * mt, M, grp);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) am[k] = cora_gelu_grad(am[k]);
+        load_rowT(am, p.S_da + srow_g * M + 64 * mt, M, grp);   // gelu'(a), parked by the forward
       }
       if (mt < 2) SUB(4 + 6 * mt);
       zero4(acc); gemm_tile(t, r, acc, i, grp); unpack(acc, dg);
