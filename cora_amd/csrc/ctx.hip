@@ -1201,6 +1201,7 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h) FAIL(-1, "eta_h is NULL");
   HCHECK(hipSetDevice(c->device));
+  if (c->infer_pending) { HCHECK(hipStreamSynchronize(c->st)); c->infer_pending = false; }   // an abandoned cora_infer(out = NULL) still reads the pinned staging
   const int L = c->L;
   int rc = upload_x(c, x, x_on_device);   // host x: staged synchronously by the runtime; device x: valid until we return
   if (rc) return rc;

@@ -35,6 +35,7 @@ CASES = {
     "d64_h2_fused": ((3, 32, 32), 4, 64, 2, 3, 3, 4),      # fused kernel, head dim 32
     "d64_h4_fused_12block": ((3, 32, 32), 4, 64, 4, 12, 2, 3),   # fused kernel, head dim 16 (a 12-block sweep point)
     "cfg3_shape_B2": ((3, 32, 32), 4, 128, 4, 12, 2, 3),
+    "n36_h2_ragged_chunk": ((3, 24, 24), 4, 32, 2, 2, 2, 3),   # N = 36: masked rows in the single-chunk attention kernels
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
