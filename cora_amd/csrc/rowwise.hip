@@ -376,11 +376,15 @@ __global__ __launch_bounds__(256) void vode_grad_kernel(VodeGradP p) {
       ss += (double)(gv.x * gv.x + gv.y * gv.y) + (double)(gv.z * gv.z + gv.w * gv.w);
     }
   }
-  double tot = block_sum_256(ss, sh);
-  if (threadIdx.x == 0) atomicAdd(&p.sumsq[v * 8 + (blockIdx.x & 7)], tot);
+  // both sums through the wave shuffles together, one barrier for the pair
+  __shared__ double sh2[8];
+  double a = wave_sum_d(ss), b = wave_sum_d((double)en);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh2[w] = a; sh2[4 + w] = b; }
   __syncthreads();
-  tot = block_sum_256((double)en, sh);
-  if (threadIdx.x == 0) atomicAdd(&p.esum[v * 8 + (blockIdx.x & 7)], tot);
+  if (threadIdx.x == 0) atomicAdd(&p.sumsq[v * 8 + (blockIdx.x & 7)], sh2[0] + sh2[1] + sh2[2] + sh2[3]);
+  if (threadIdx.x == 64) atomicAdd(&p.esum[v * 8 + (blockIdx.x & 7)], sh2[4] + sh2[5] + sh2[6] + sh2[7]);
+  (void)sh;
 }
 void launch_vode_grad(const VodeGradP& p, hipStream_t st) {
   long long nl4 = p.nl / 4;
