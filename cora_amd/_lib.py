@@ -68,6 +68,8 @@ SIGNATURES = {
     "cora_forward": (C.c_int, [_P, _P, _SZ]),
     "cora_energy": (C.c_int, [_P, _P, _DP, _P, _P, _SZ]),
     "cora_unmask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
+    "cora_unmask_learn": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, C.c_float, _P, _P, _P, _P]),
+    "cora_dbg_stamps": (C.c_int, [_P, _P, _SZ]),
     "cora_profile_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "cora_sync": (C.c_int, [_P]),
 }

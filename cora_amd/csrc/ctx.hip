@@ -143,6 +143,16 @@ int dalloc(cora_ctx* c, float** p, long long n) {
   return 0;
 }
 
+// A cora_infer(out = NULL) may still be in flight and still reads the pinned staging buffers and the
+// vodes: every entry point that touches vodes, eta_dev, xp or the energy log ends it first.
+int settle_pending(cora_ctx* c) {
+  if (!c->infer_pending) return 0;
+  HCHECK(hipSetDevice(c->device));
+  HCHECK(hipStreamSynchronize(c->st));
+  c->infer_pending = false;
+  return 0;
+}
+
 float* vode_ptr(cora_ctx* c, float* base, int l) { return l == 0 ? base : base + c->n0 + (long long)(l - 1) * c->nl; }
 float* err_ptr(cora_ctx* c, int l) { return c->Es + (long long)(l - 1) * c->nl; }  // l = 1..L+1 ; L+2 = e_img
 
@@ -780,6 +790,7 @@ static int copy_in(cora_ctx* c, float* dst, const float* host, size_t n, size_t 
   if (!host) FAIL(-1, "null host pointer");
   if (n != expect) FAIL(-1, "size mismatch");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   HCHECK(hipMemcpyAsync(dst, host, n * sizeof(float), hipMemcpyHostToDevice, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   return 0;
@@ -788,6 +799,7 @@ static int copy_out(cora_ctx* c, float* host, const float* src, size_t n, size_t
   if (!host) FAIL(-1, "null host pointer");
   if (n != expect) FAIL(-1, "size mismatch");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   HCHECK(hipMemcpyAsync(host, src, n * sizeof(float), hipMemcpyDeviceToHost, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   return 0;
@@ -838,6 +850,7 @@ int cora_get_vode_grad(cora_ctx* c, int l, float* host, size_t n) {
 int cora_init_vodes(cora_ctx* c, const float* h0) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   if (h0) HCHECK(hipMemcpyAsync(c->Hs, h0, sizeof(float) * (size_t)c->n0, hipMemcpyHostToDevice, c->st));
   else HCHECK(hipMemsetAsync(c->Hs, 0, sizeof(float) * (size_t)c->n0, c->st));
   int rc = chain_forward(c, true);
@@ -908,7 +921,7 @@ int cora_infer(cora_ctx* c, const float* x, int x_on_device, int T, const float*
   // flight and cora_wgrad, which must follow, ends it -- one host synchronisation less per batch on
   // the data-parallel path.  eta_h then goes through the ctx's pinned staging buffer.
   const bool deferred = !out && c->use_graph && !c->prof;
-  if (c->infer_pending) { HCHECK(hipStreamSynchronize(c->st)); c->infer_pending = false; }
+  if (int rc_ = settle_pending(c)) return rc_;
   int rc = upload_x(c, x, x_on_device);
   if (rc) return rc;
   if (deferred) {
@@ -1059,11 +1072,12 @@ int enqueue_apply(cora_ctx* c, float scale_by) {
   return rc ? rc : enqueue_recon(c);
 }
 
-// host side of one AdamW step: advance the count and stage {eta_w, 1 - b1^count, 1 - b2^count}
+// host side of one AdamW step: stage {eta_w, 1 - b1^count, 1 - b2^count} for count = adam_count + 1
+// (the caller advances adam_count once the launches that consume them are enqueued)
 int stage_adam_hyp(cora_ctx* c, float eta_w) {
-  c->adam_count += 1;
-  float h[4] = {eta_w, (float)(1.0 - pow((double)c->cfg.adam_b1, (double)c->adam_count)),
-                (float)(1.0 - pow((double)c->cfg.adam_b2, (double)c->adam_count)), 0.f};
+  const double cnt = (double)(c->adam_count + 1);
+  float h[4] = {eta_w, (float)(1.0 - pow((double)c->cfg.adam_b1, cnt)),
+                (float)(1.0 - pow((double)c->cfg.adam_b2, cnt)), 0.f};
   HCHECK(hipMemcpyAsync(c->hyp_dev, h, sizeof h, hipMemcpyHostToDevice, c->st));
   HCHECK(hipStreamSynchronize(c->st));   // h is a stack buffer
   return 0;
@@ -1148,6 +1162,7 @@ int cora_apply_wgrad(cora_ctx* c, float eta_w, float scale_by, cora_step_out* ou
   HCHECK(hipEventRecord(c->ev0, c->st));
   if (graphed) HCHECK(hipGraphLaunch(c->apply_graph, c->st));
   else if ((rc = enqueue_apply(c, scale_by))) return rc;
+  c->adam_count += 1;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   c->learn_warm = true;
@@ -1185,7 +1200,7 @@ int infer_graph(cora_ctx* c, int T, hipGraphExec_t* out) {
 int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, float eta_w, cora_step_out* out) {
   if (!c) return -1;
   if (!c->use_graph || c->prof || !c->learn_warm) {   // eager: the three public phases back to back
-    c->learn_warm = true;   // every learning-phase kernel has run once outside stream capture after this
+    // (cora_apply_wgrad sets learn_warm once every learning-phase kernel has run outside stream capture)
     cora_step_out tmp; memset(&tmp, 0, sizeof tmp);
     int rc = cora_infer(c, x, x_on_device, T, eta_h, &tmp);
     if (rc) return rc;
@@ -1201,18 +1216,18 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h) FAIL(-1, "eta_h is NULL");
   HCHECK(hipSetDevice(c->device));
-  if (c->infer_pending) { HCHECK(hipStreamSynchronize(c->st)); c->infer_pending = false; }   // an abandoned cora_infer(out = NULL) still reads the pinned staging
+  if (int rc_ = settle_pending(c)) return rc_;   // an abandoned cora_infer(out = NULL) still reads the pinned staging
   const int L = c->L;
   int rc = upload_x(c, x, x_on_device);   // host x: staged synchronously by the runtime; device x: valid until we return
   if (rc) return rc;
   // eta_h and the AdamW scalars go through pinned memory the ctx owns: asynchronous, and the call
   // ends with a stream synchronisation before that memory is written again
-  c->adam_count += 1;
+  const double cnt = (double)(c->adam_count + 1);
   memcpy(c->host_in, eta_h, sizeof(float) * T);
   float* hy = c->host_in + c->Tmax;
   hy[0] = eta_w;
-  hy[1] = (float)(1.0 - pow((double)c->cfg.adam_b1, (double)c->adam_count));
-  hy[2] = (float)(1.0 - pow((double)c->cfg.adam_b2, (double)c->adam_count));
+  hy[1] = (float)(1.0 - pow((double)c->cfg.adam_b1, cnt));
+  hy[2] = (float)(1.0 - pow((double)c->cfg.adam_b2, cnt));
   hy[3] = 0.f;
   HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
   HCHECK(hipMemcpyAsync(c->hyp_dev, hy, sizeof(float) * 4, hipMemcpyHostToDevice, c->st));
@@ -1234,6 +1249,7 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   HCHECK(hipGraphLaunch(gi, c->st));
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipGraphLaunch(c->learn_graph, c->st));
+  c->adam_count += 1;
   HCHECK(hipEventRecord(c->ev2, c->st));
   // scalars back through pinned memory: [energy row of step T-1 (slots or plain)] [w-energy row] [mse sum]
   double* ho = c->host_out;
@@ -1263,11 +1279,13 @@ int cora_infer_begin(cora_ctx* c, const float* x, int x_on_device, int T, const 
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h) FAIL(-1, "eta_h is NULL");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   int rc = upload_x(c, x, x_on_device);
   if (rc) return rc;
   HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   c->last_T = T;
+  HCHECK(hipEventRecord(c->ev0, c->st));
   zero_infer_logs(c, T);
   return 0;
 }
@@ -1297,8 +1315,12 @@ int cora_infer_update(cora_ctx* c, int t) {
 int cora_infer_end(cora_ctx* c, cora_step_out* out) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
+  HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out && c->last_T > 0) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    out->infer_ms = ms;
     std::vector<double> en((size_t)c->L + 3);
     if (energy_row(c, c->last_T - 1, en.data())) FAIL(-2, "energy read-back failed");
     double tot = 0.0;
@@ -1315,6 +1337,7 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h || !eta_w) FAIL(-1, "eta_h / eta_w is NULL");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   const int L = c->L;
   int rc = upload_x(c, x, x_on_device);
   if (rc) return rc;
@@ -1329,7 +1352,6 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
   HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
   HCHECK(hipMemcpyAsync(c->hyp_dev + 4, hy.data(), sizeof(float) * hy.size(), hipMemcpyHostToDevice, c->st));
   HCHECK(hipStreamSynchronize(c->st));
-  c->adam_count += T;
   c->last_T = T;
   HCHECK(hipEventRecord(c->ev0, c->st));
   zero_infer_logs(c, T);
@@ -1337,6 +1359,7 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
     rc = infer_step(c, t);                                                     // :421-424
     if (!rc) rc = enqueue_wgrad(c);                                            // :426-427
     if (!rc) rc = enqueue_adamw(c, 1.0f / (float)c->B, c->hyp_dev + 4 + 4 * t);  // :428
+    if (!rc) c->adam_count += 1;
   }
   if (rc) return rc;
   HCHECK(hipEventRecord(c->ev1, c->st));
@@ -1384,6 +1407,7 @@ int cora_get_energies(cora_ctx* c, int T, double* total, double* per_layer) {
   if (!c) return -1;
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   const int W = c->L + 3;
   std::vector<double> en((size_t)T * W);
   HCHECK(hipStreamSynchronize(c->st));
@@ -1410,6 +1434,7 @@ int cora_forward(cora_ctx* c, float* xhat, size_t n) {
   if (!c) return -1;
   if (!xhat) FAIL(-1, "null output");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   int rc = chain_forward(c, false);
   if (rc) return rc;
   return download_image(c, c->z, xhat, n);
@@ -1418,6 +1443,7 @@ int cora_forward(cora_ctx* c, float* xhat, size_t n) {
 int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, float* xhat, size_t n) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   const int L = c->L, slot = c->Tmax + 1;
   if (x_host) { int rc = upload_x(c, x_host, 0); if (rc) return rc; }
   HCHECK(hipMemsetAsync(c->energies + (long long)slot * (L + 3), 0, sizeof(double) * (L + 3), c->st));
@@ -1437,16 +1463,19 @@ int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, 
   return 0;
 }
 
-// `unmask_on_batch_enhanced` (src/decoder_transformer.py:833-1046): see include/cora_hip.h
-int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const float* mask, int use_corruption,
-                int status_init, int T, const float* eta_h, float alpha, float* recons, float* xhat,
-                float* sensory, double* grad_norms) {
+// `unmask_on_batch_enhanced` (src/decoder_transformer.py:833-1046): see include/cora_hip.h.
+// eta_w != NULL: `update_weights_during_unmasking` (:967-979) -- after every vode step, dE/dW at the
+// updated vodes and one clip + AdamW step with scale `scale_by`, before the clamp.
+static int unmask_impl(cora_ctx* c, const float* x_true, const float* x_init, const float* mask, int use_corruption,
+                       int status_init, int T, const float* eta_h, float alpha, float* recons, float* xhat,
+                       float* sensory, double* grad_norms, const float* eta_w, float scale_by) {
   if (!c) return -1;
   if (T < 0 || T > c->Tmax) FAIL(-1, "T out of range (0..max_T)");
   if (!x_true || !x_init) FAIL(-1, "x_true / x_init is NULL");
   if (T > 0 && !eta_h) FAIL(-1, "eta_h is NULL");
   if (use_corruption && !mask) FAIL(-1, "use_corruption needs a mask");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   const int L = c->L;
   int rc = 0;
   if (use_corruption && !c->msens) {
@@ -1462,6 +1491,18 @@ int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const flo
   if ((rc = upload_x(c, x_init, 0))) return rc;             // forward(x_init): the sensory vode takes x_init, :900-901
   if (status_init && (rc = chain_forward(c, true))) return rc;   // STATUS.INIT: h_l := u_l chained from h_0
   if (T > 0) HCHECK(hipMemcpyAsync(c->eta_dev, eta_h, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  std::vector<float> hy;
+  if (eta_w && T > 0) {
+    hy.resize((size_t)4 * T);
+    for (int t = 0; t < T; ++t) {
+      const double cnt = (double)(c->adam_count + t + 1);
+      hy[4 * t] = eta_w[t];
+      hy[4 * t + 1] = (float)(1.0 - pow((double)c->cfg.adam_b1, cnt));
+      hy[4 * t + 2] = (float)(1.0 - pow((double)c->cfg.adam_b2, cnt));
+      hy[4 * t + 3] = 0.f;
+    }
+    HCHECK(hipMemcpyAsync(c->hyp_dev + 4, hy.data(), sizeof(float) * hy.size(), hipMemcpyHostToDevice, c->st));
+  }
   HCHECK(hipStreamSynchronize(c->st));
   launch_zero(c->energies, ((sizeof(double) * (size_t)(T + 1) * (L + 3)) + 15) / 16 * 16, c->st);
   launch_zero(c->sumsq, sizeof(double) * (size_t)(T + 1) * (L + 2) * 8, c->st);
@@ -1475,6 +1516,11 @@ int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const flo
       if ((rc = download_image(c, c->z, recons + (size_t)t * c->nImg, (size_t)c->nImg))) break;
     }
     if ((rc = infer_step(c, t))) break;                      // :922-965
+    if (eta_w) {                                             // :967-979
+      if ((rc = enqueue_wgrad(c))) break;
+      if ((rc = enqueue_adamw(c, scale_by, c->hyp_dev + 4 + 4 * t))) break;
+      c->adam_count += 1;
+    }
     if (use_corruption) launch_sens_clamp(c->xp, c->xt, c->mk, alpha, c->n0, c->st);   // :982-994
   }
   c->sens_live = false;                                      // re-frozen, :1037
@@ -1503,10 +1549,26 @@ int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const flo
   return 0;
 }
 
+int cora_unmask(cora_ctx* c, const float* x_true, const float* x_init, const float* mask, int use_corruption,
+                int status_init, int T, const float* eta_h, float alpha, float* recons, float* xhat,
+                float* sensory, double* grad_norms) {
+  return unmask_impl(c, x_true, x_init, mask, use_corruption, status_init, T, eta_h, alpha, recons, xhat, sensory,
+                     grad_norms, nullptr, 0.f);
+}
+int cora_unmask_learn(cora_ctx* c, const float* x_true, const float* x_init, const float* mask, int use_corruption,
+                      int status_init, int T, const float* eta_h, float alpha, const float* eta_w, float scale_by,
+                      float* recons, float* xhat, float* sensory, double* grad_norms) {
+  if (!c) return -1;
+  if (!eta_w) FAIL(-1, "eta_w is NULL");
+  return unmask_impl(c, x_true, x_init, mask, use_corruption, status_init, T, eta_h, alpha, recons, xhat, sensory,
+                     grad_norms, eta_w, scale_by);
+}
+
 int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* ms, double* flops, double* bytes, int* n_out) {
   if (!c) return -1;
   if (cap < K_COUNT) FAIL(-1, "profile: capacity too small");
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
   // snapshot the vodes + momentum so profiling does not disturb the trajectory
   float *hsave = nullptr, *msave = nullptr;
   HCHECK(hipMalloc((void**)&hsave, sizeof(float) * (size_t)c->nV));

@@ -7,11 +7,14 @@ batch: the SUM over ranks of the flat dE/dW buffer, after which every rank appli
 clip + AdamW update with scale_by = 1/(B_local * k).  Inference (T vode steps) needs no collective.
 
 optax.clip_by_global_norm on the vode gradients couples the whole batch every inference step.
-Two modes: 'local' (default, fast: the whole T-step loop stays one captured graph and each shard
-clips by its own norm -- identical to the reference whenever no shard clips) and
-`exact_clip=True` (the per-vode sums of squares are all-reduced between the gradient half and the
-update half of every inference step -- the reference's trajectory for the global batch, at the
-price of one host round trip per step).
+Two modes: 'local' (fast: the whole T-step loop stays one captured graph and each shard clips by
+its own norm -- identical to the reference only when no shard clips AND `use_vode_grad_norm` is
+off) and `exact_clip=True` (the per-vode sums of squares are all-reduced between the gradient half
+and the update half of every inference step -- the reference's trajectory for the global batch, at
+the price of one host round trip per step).  `normalize_vode_h_gradients`
+(/root/reference/src/decoder_transformer.py:353-389) divides every leaf by its WHOLE-batch norm on
+every step, so with `use_vode_grad_norm` a sharded run is only meaningful in the exact mode:
+DataParallel switches to it (with a warning) when the world has more than one rank.
 """
 from __future__ import annotations
 
@@ -43,8 +46,15 @@ class DataParallel:
         import torch
         import ctypes as C
         from . import _lib
+        import warnings
+        import torch.distributed as dist
         self.group = group
         self.exact_clip = bool(exact_clip)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world > 1 and bool(model.config.use_vode_grad_norm) and not self.exact_clip:
+            warnings.warn("use_vode_grad_norm normalises each vode gradient by its whole-batch norm on every "
+                          "step: data-parallel shards need the batch-global sums -> exact_clip=True")
+            self.exact_clip = True
         ctx = model._ensure_ctx(batch_size)
         dev = torch.device("cuda", model.device)
         self.buf = torch.zeros(model._nW, dtype=torch.float32, device=dev)

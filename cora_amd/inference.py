@@ -43,7 +43,8 @@ def make_mask(model: TransformerDecoder, x_batch: np.ndarray, corrupt_ratio: flo
 
 
 def _run_unmask(model: TransformerDecoder, optim_h: Optim, x_true, x_init, mask, use_corruption: bool,
-                T: int, want_recons: bool, want_norms: bool):
+                T: int, want_recons: bool, want_norms: bool, normalise: bool = False,
+                optim_w: Optional[Optim] = None, w_scale_by: float = 1.0):
     lib = _lib.load()
     B = x_true.shape[0]
     if model.config.use_status_init_in_unmasking:
@@ -54,8 +55,12 @@ def _run_unmask(model: TransformerDecoder, optim_h: Optim, x_true, x_init, mask,
     if T > model.max_T:
         raise ValueError(f"T={T} exceeds the model's max_T={model.max_T}")
     rh = optim_h._recipe()
-    model._grad_options(True)
-    model._apply_recipes_h(optim_h)
+    # unmask_on_batch_enhanced only scales (:925-933); the linear-probe extractor also normalises
+    model._grad_options(True, normalise)
+    if optim_w is not None:
+        _, rw = model._apply_recipes(optim_w, optim_h)
+    else:
+        model._apply_recipes_h(optim_h)
     optim_h.clear()
     optim_h.init()                                                            # :840-841
     eta = np.array([lr_at(rh.base.learning_rate, t) for t in range(max(T, 1))], dtype=np.float32)
@@ -68,12 +73,16 @@ def _run_unmask(model: TransformerDecoder, optim_h: Optim, x_true, x_init, mask,
     if use_corruption:
         mk = np.ascontiguousarray(np.broadcast_to(mask.reshape((B, 1) + mask.shape[-2:]) if mask.ndim == 4 else mask, shape),
                                   dtype=np.float32)
-    _lib.check(lib.cora_unmask(
-        ctx, _fptr(x_true), _fptr(x_init), _fptr(mk) if mk is not None else None, int(use_corruption),
-        0, int(T), _fptr(eta),
-        C.c_float(float(model.config.inference_clamp_alpha)),
-        _fptr(recons) if recons is not None else None, _fptr(xhat), _fptr(sens),
-        _fptr(norms) if norms is not None else None), ctx)
+    head = (ctx, _fptr(x_true), _fptr(x_init), _fptr(mk) if mk is not None else None, int(use_corruption),
+            0, int(T), _fptr(eta), C.c_float(float(model.config.inference_clamp_alpha)))
+    tail = (_fptr(recons) if recons is not None else None, _fptr(xhat), _fptr(sens),
+            _fptr(norms) if norms is not None else None)
+    if optim_w is not None and T > 0:     # update_weights_during_unmasking, :967-979
+        eta_w = np.array([lr_at(rw.base.learning_rate, optim_w.count + t) for t in range(T)], dtype=np.float32)
+        _lib.check(lib.cora_unmask_learn(*head, _fptr(eta_w), C.c_float(w_scale_by), *tail), ctx)
+        optim_w.count += T
+    else:
+        _lib.check(lib.cora_unmask(*head, *tail), ctx)
     optim_h.clear()                                                           # :999
     model._x_host = sens.copy()      # the sensory vode keeps its final (blended) value, re-frozen :1037
     return recons, xhat, norms
@@ -86,12 +95,10 @@ def unmask_on_batch_enhanced(use_corruption: bool, corrupt_ratio: float, target_
     (loss, all_reconstructions, mask, inference_grad_norms_log): the masked/unmasked-balanced MSE
     (:1006-1034), the max(target_T_values) per-step status-"forward" reconstructions (:916-919),
     the mask [B,1,H,W] (zeros_like(x) without corruption, :1033-1034) and, if asked, the per-step
-    L2 norms of the scaled vode gradients (:936-958).
-
-    Not carried over: `update_weights_during_unmasking` (:967-979, off in every named config)."""
+    L2 norms of the scaled vode gradients (:936-958).  With `config.update_weights_during_unmasking`
+    and an `optim_w`, every vode step is followed by a weight step scaled by 1 / x.shape[0] (:967-979)."""
     model.eval()
-    if model.config.update_weights_during_unmasking and optim_w is not None:
-        raise NotImplementedError("update_weights_during_unmasking is not supported (off in every named config)")
+    learn = bool(model.config.update_weights_during_unmasking) and optim_w is not None
     x = _check_x(model, x)
     expected_bs = model._B if model._ctx is not None else x.shape[0]
     x_batch = np.repeat(x, expected_bs, axis=0) if x.shape[0] != expected_bs else x   # :857-860
@@ -102,7 +109,8 @@ def unmask_on_batch_enhanced(use_corruption: bool, corrupt_ratio: float, target_
     if use_corruption:
         mask, x_init = make_mask(model, x_batch, corrupt_ratio, rng)
     recons, xhat, norms = _run_unmask(model, optim_h, x_batch, x_init, mask, bool(use_corruption), max_T,
-                                      True, log_inference_grads)
+                                      True, log_inference_grads, optim_w=optim_w if learn else None,
+                                      w_scale_by=1.0 / x.shape[0])
     all_recons = [recons[t] for t in range(max_T)] if recons is not None else []
     xc = np.clip(xhat.astype(np.float64), 0.0, 1.0)
     if use_corruption:
@@ -128,7 +136,8 @@ def extract_features_from_batch(x_batch, model: TransformerDecoder, optim_h: Opt
     sensory vode frozen, then concatenate the chosen vodes' h on the last axis and, if asked,
     average over the token axis."""
     x = _check_x(model, x_batch)
-    _run_unmask(model, optim_h, x, x, None, False, int(inference_steps_for_extraction), False, False)
+    _run_unmask(model, optim_h, x, x, None, False, int(inference_steps_for_extraction), False, False,
+                normalise=True)                              # examples/linear_probe.py:223-232: scaling AND normalisation
     n_vodes = model.L + 3
     feats = []
     for idx in target_vode_indices_list:

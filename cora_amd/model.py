@@ -349,14 +349,17 @@ class TransformerDecoder:
             self._optim_sig = sig
         return rh, rw
 
-    def _grad_options(self, conditioned: bool):
-        """Layer scaling / per-leaf normalisation as configured (MODE 2, inference-only loops), or off
-        (MODE 1 of train_on_batch applies the raw gradients, reference :421-424)."""
+    def _grad_options(self, scaling: bool, normalise: Optional[bool] = None):
+        """Which gradient conditioning the next loop applies, out of what the config enables.
+        MODE 2 of train_on_batch (reference :449-460) and the linear-probe extractor
+        (examples/linear_probe.py:223-232): layer scaling and per-leaf normalisation.
+        unmask_on_batch_enhanced (:925-933): layer scaling only.  MODE 1 (:421-424): neither."""
         c = self.config
+        normalise = scaling if normalise is None else normalise
         _lib.check(_lib.load().cora_set_grad_options(
-            self._ctx, int(bool(c.use_inference_lr_scaling) and conditioned),
+            self._ctx, int(bool(c.use_inference_lr_scaling) and scaling),
             C.c_float(float(c.inference_lr_scale_base if c.inference_lr_scale_base is not None else 1.0)),
-            int(bool(c.use_vode_grad_norm) and conditioned), C.c_float(float(c.vode_grad_norm_target))), self._ctx)
+            int(bool(c.use_vode_grad_norm) and normalise), C.c_float(float(c.vode_grad_norm_target))), self._ctx)
 
     def _apply_recipes_h(self, optim_h: Optim):
         """Vode-optimizer half only (inference-only loops); the weight half keeps its last values."""
@@ -371,6 +374,14 @@ class TransformerDecoder:
         return rh
 
     # -- adam state (optimizer state is not part of the reference's checkpoints, but is exposed) ----
+    def _reset_adam_state(self):
+        """optim_w.init(model): AdamW moments and count back to zero (no-op before the ctx exists: a
+        fresh ctx starts from zeros)."""
+        if self._ctx is None:
+            return
+        z = np.zeros(self._nW, dtype=np.float32)
+        _lib.check(_lib.load().cora_set_adam_state(self._ctx, _fptr(z), _fptr(z), 0), self._ctx)
+
     def get_adam_state(self):
         mu = np.empty(self._nW, dtype=np.float32)
         nu = np.empty(self._nW, dtype=np.float32)

@@ -97,8 +97,13 @@ class Optim:
             self.init(parameters)
 
     def init(self, parameters=None) -> None:
+        """(Re-)initialise the optimizer state (pcx/utils/_optim.py:150-163): the schedule count restarts
+        and, for an AdamW recipe bound to a model, the moments and the bias-correction count on the
+        device are zeroed with it -- in the reference mu, nu and count are one optax state."""
         self.recipe = _as_chain(self.optax_opt_fn())
         self.count = 0
+        if parameters is not None and isinstance(self.recipe.base, adamw) and hasattr(parameters, "_reset_adam_state"):
+            parameters._reset_adam_state()
 
     def clear(self) -> None:
         self.recipe = None

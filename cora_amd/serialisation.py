@@ -5,7 +5,9 @@ Same file format as /root/reference/pcx/utils/_serialisation.py:25-105: one
 (".patch_projection.nn.weight", ".transformer_blocks[0].attention.nn.query_proj.weight",
 ".vodes[0].h", ...), so checkpoints written by the reference driver
 (examples/debug_transformer_wandb.py:1278) load here and vice versa.
-`filter` accepts the same spellings: a class or union of classes out of LayerParam / VodeParam.
+`filter` accepts the same spellings: a class or union of classes out of LayerParam / VodeParam, or a
+predicate on a parameter object (the reference's `Callable[[Any], bool]`, :28,41-45), which is asked
+once per parameter family with one of that family's proxies.
 """
 from __future__ import annotations
 
@@ -18,39 +20,47 @@ from .model import LayerParam, TransformerDecoder, VodeParam
 from .params import vode_key
 
 
-def _wants(filter, cls) -> bool:
+def _wants(filter, cls, sample=None) -> bool:
     if isinstance(filter, UnionType):
         return cls in filter.__args__
     if isinstance(filter, type):
         return issubclass(cls, filter)
     if isinstance(filter, (tuple, list)):
         return cls in filter
-    raise TypeError("filter must be LayerParam, VodeParam or a union of them")
+    if callable(filter):
+        return bool(filter(sample))
+    raise TypeError("filter must be LayerParam, VodeParam, a union of them or a predicate")
+
+
+def _samples(model):
+    return model.vodes[0].h, model.patch_projection.nn.weight
 
 
 def save_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
     data: Dict[str, np.ndarray] = {}
-    if _wants(filter, VodeParam):
+    sv, sl = _samples(model)
+    if _wants(filter, VodeParam, sv):
         for l in range(model.L + 3):
             v = model.vodes[l].h.get()
             if v is not None:
                 data[vode_key(l)] = v
-    if _wants(filter, LayerParam):
+    if _wants(filter, LayerParam, sl):
         data.update(model.get_weights())
     np.savez_compressed(path, **data)
 
 
 def load_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
     path = path if path.endswith(".npz") else f"{path}.npz"
+    sv, sl = _samples(model)
     with np.load(path) as loaded:          # allow_pickle stays False
-        if _wants(filter, LayerParam):
+        if _wants(filter, LayerParam, sl):
             weights = {}
             for key in model.param_keys():
                 if key not in loaded:
                     raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
                 weights[key] = loaded[key]
             model.set_weights(weights)
-        if _wants(filter, VodeParam):
+        if _wants(filter, VodeParam, sv):
             for l in range(model.L + 3):
                 key = vode_key(l)
                 if key not in loaded:

@@ -131,9 +131,10 @@ int cora_infer(cora_ctx* ctx, const float* x, int x_on_device, int T, const floa
 int cora_wgrad(cora_ctx* ctx, cora_step_out* out);
 int cora_apply_wgrad(cora_ctx* ctx, float eta_w, float scale_by, cora_step_out* out);
 /* Gradient conditioning of the vode step, changeable after cora_create: exponential layer scaling
- * (:308-350) and per-leaf normalisation (:353-389).  The reference applies them in MODE 2 of
- * train_on_batch and in the inference-only loops, but not in MODE 1 (:421-424), so a host that mixes
- * the two switches here.  Drops the captured inference graphs when something changes. */
+ * (:308-350) and per-leaf normalisation (:353-389).  The reference applies both in MODE 2 of
+ * train_on_batch (:449-460) and in the linear-probe extractor (examples/linear_probe.py:223-232),
+ * only the scaling in unmask_on_batch_enhanced (:925-933) and neither in MODE 1 (:421-424), so a host
+ * that mixes them switches here.  Drops the captured inference graphs when something changes. */
 int cora_set_grad_options(cora_ctx* ctx, int use_scaling, float scale_base, int use_grad_norm, float grad_norm_target);
 
 /* MODE 1 of train_on_batch, `update_weights_every_inference_step` (iPC,
@@ -188,6 +189,15 @@ int cora_unmask(cora_ctx* ctx, const float* x_true, const float* x_init, const f
                 int use_corruption, int status_init, int T, const float* eta_h, float alpha,
                 float* recons, float* xhat, float* sensory, double* grad_norms);
 
+/* The same loop with `update_weights_during_unmasking` (:967-979): after every vode step, dE/dW at the
+ * updated vodes (target = the current sensory state) and one clip + AdamW weight step with learning
+ * rate eta_w[t] and gradient scale `scale_by` (the reference passes 1 / x.shape[0], :978), before the
+ * clamp.  The AdamW count advances by T. */
+int cora_unmask_learn(cora_ctx* ctx, const float* x_true, const float* x_init, const float* mask,
+                      int use_corruption, int status_init, int T, const float* eta_h, float alpha,
+                      const float* eta_w, float scale_by, float* recons, float* xhat, float* sensory,
+                      double* grad_norms);
+
 /* `energy(model=...)` (:302-305) with the sensory vode set to x (host, may be NULL to keep the
  * last one): batch-summed E, per-vode E [L+3] (may be NULL) and the status-None prediction. */
 int cora_energy(cora_ctx* ctx, const float* x_host, double* E, double* per_layer,
@@ -199,6 +209,10 @@ int cora_energy(cora_ctx* ctx, const float* x_host, double* E, double* per_layer
 int cora_profile_step(cora_ctx* ctx, int cap, char* names, int* launches, double* ms,
                       double* flops, double* bytes, int* n_out);
 int cora_sync(cora_ctx* ctx);
+/* Diagnostic builds only (`make -C cora_amd/csrc stamps`, -DCORA_STAMPS): the first call allocates the
+ * per-workgroup s_memtime stamp table of the fused kernel, later calls copy it out ((L+1)*B*16 words).
+ * In the shipped library the kernels never write it.  No counterpart in the reference. */
+int cora_dbg_stamps(cora_ctx* ctx, unsigned long long* host, size_t n_words);
 
 #ifdef __cplusplus
 }

@@ -295,14 +295,16 @@ def h_gradients(h, W, pos, y, dims, hp: Hyper):
     return E.detach(), [e.detach() for e in Es], grads, us[-1].detach()
 
 
-def scale_h_grads(grads, dims: Dims, hp: Hyper):
-    """apply_exponential_layer_scaling (:308-350) then normalize_vode_h_gradients (:353-389)."""
+def scale_h_grads(grads, dims: Dims, hp: Hyper, normalise: bool = True):
+    """apply_exponential_layer_scaling (:308-350) then, where the caller does so, normalize_vode_h_gradients
+    (:353-389).  train_on_batch MODE 2 (:449-460) and examples/linear_probe.py:223-232 do both;
+    unmask_on_batch_enhanced (:925-933) only scales."""
     out = list(grads)
     if hp.use_scaling:
         base = hp.scale_base if hp.scale_base is not None else 1.0
         base_idx = dims.L + 1
         out = [g * (base ** float(base_idx - l)) for l, g in enumerate(out)]
-    if hp.use_grad_norm:
+    if hp.use_grad_norm and normalise:
         out = [g / (torch.sqrt((g * g).sum()) + 1e-8) * hp.grad_norm_target for g in out]
     return out
 
@@ -403,7 +405,8 @@ def energy_and_prediction(h, weights, pos, x, dims: Dims, hp: Hyper, dtype=torch
 def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Optional[np.ndarray],
                     weights, h: List[np.ndarray], pos, dims: Dims, hp: Hyper, eta_h: Sequence[float],
                     alpha: float = 1.0, use_corruption: bool = True, status_init: bool = False,
-                    dtype=torch.float64):
+                    dtype=torch.float64, normalise: bool = False, eta_w: Optional[Sequence[float]] = None,
+                    adam: Optional[AdamState] = None, scale_by: Optional[float] = None):
     """`unmask_on_batch_enhanced` (src/decoder_transformer.py:833-1046), the inference-only /
     inpainting loop.  x_init is what the sensory vode starts from (the corrupted image, :896,900-901),
     mask is [B,1,H,W] with 1 = masked (:882-894).  With use_corruption the sensory vode is un-frozen
@@ -413,11 +416,18 @@ def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Option
     status_init: the INIT pass of :899-901 re-chains h_l := u_l from h_0 (h_0 itself is kept: the
     reference re-draws it from its own RNG, which is not reproduced).  Returns the per-step
     status-"forward" reconstructions (:916-919), the final one (:1002-1004), the loss (:1006-1032)
-    and the final states."""
+    and the final states.
+    normalise: False = unmask_on_batch_enhanced (layer scaling only, :925-933); True = the linear-probe
+    extractor (examples/linear_probe.py:223-232), which also normalises each leaf.
+    eta_w: `update_weights_during_unmasking` (:967-979): after every vode step, dE/dW at the updated
+    vodes and one clip + AdamW step with scale_by (= 1/x.shape[0], :978)."""
     W = {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
     pos_t = torch.as_tensor(np.asarray(pos), dtype=dtype)
     hs = [torch.as_tensor(np.asarray(t), dtype=dtype) for t in h]
     xt = torch.as_tensor(np.asarray(x_true), dtype=dtype)
+    if eta_w is not None:
+        adam = adam if adam is not None else AdamState()
+        scale_by = scale_by if scale_by is not None else 1.0 / xt.shape[0]
     hsens = torch.as_tensor(np.asarray(x_init), dtype=dtype).clone()
     if status_init:
         with torch.no_grad():
@@ -439,12 +449,31 @@ def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Option
         grads = torch.autograd.grad(E, hv, allow_unused=True)
         grads = [g if g is not None else torch.zeros_like(s) for g, s in zip(grads, hv)]
         energies.append(float(E.detach()))
-        g_scaled = scale_h_grads(grads, dims, hp)        # vode index L+2 -> base^-1
+        g_scaled = scale_h_grads(grads, dims, hp, normalise)        # vode index L+2 -> base^-1
         norms.append([float(torch.sqrt((g * g).sum())) for g in g_scaled])
         g_clip = _clip(g_scaled, hp.clip_h)
         mom = [g + hp.momentum * m for g, m in zip(g_clip, mom)]
         state = [s - eta_h[t] * m for s, m in zip(state, mom)]
         hs = state[:dims.L + 2]
+        if eta_w is not None:                              # :967-979, before the clamp
+            ysens = state[-1] if use_corruption else hsens
+            Wg = {k: v.detach().clone().requires_grad_(True) for k, v in W.items()}
+            us_w = predictions(hs, Wg, pos_t, dims)
+            Ew = sum(layer_energies(hs, us_w, ysens, hp.l1, hp.l2))
+            keys = list(Wg.keys())
+            wg = torch.autograd.grad(Ew, [Wg[k] for k in keys])
+            g_list = _clip([g.detach() * scale_by for g in wg], hp.clip_w)
+            adam.count += 1
+            newW = {}
+            for k, g in zip(keys, g_list):
+                mu = torch.as_tensor(adam.mu.get(k, np.zeros(g.shape)), dtype=dtype)
+                nu = torch.as_tensor(adam.nu.get(k, np.zeros(g.shape)), dtype=dtype)
+                mu = hp.b1 * mu + (1 - hp.b1) * g
+                nu = hp.b2 * nu + (1 - hp.b2) * g * g
+                upd = (mu / (1 - hp.b1 ** adam.count)) / (torch.sqrt(nu / (1 - hp.b2 ** adam.count)) + hp.eps) + hp.wd * W[k]
+                newW[k] = W[k] - eta_w[t] * upd
+                adam.mu[k], adam.nu[k] = mu.numpy(), nu.numpy()
+            W = newW
         if use_corruption:
             cur = state[-1]
             target = torch.where(mk == 0, xt, cur)
@@ -460,7 +489,8 @@ def unmask_on_batch(T: int, x_true: np.ndarray, x_init: np.ndarray, mask: Option
     else:
         loss = ((xhat.clamp(0.0, 1.0).reshape(-1) - xt.reshape(-1)) ** 2).mean()
     return {"recons": recons, "xhat": xhat.numpy(), "loss": float(loss), "energies": np.array(energies),
-            "grad_norms": np.array(norms), "h": [t.numpy() for t in hs], "sensory": hsens.numpy()}
+            "grad_norms": np.array(norms), "h": [t.numpy() for t in hs], "sensory": hsens.numpy(),
+            "weights": {k: v.detach().numpy() for k, v in W.items()}}
 
 
 def train_on_batch_ipc(T: int, x: np.ndarray, weights: Dict[str, np.ndarray], h: List[np.ndarray], pos: np.ndarray,

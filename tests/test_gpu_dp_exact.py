@@ -30,8 +30,9 @@ def _free_port():
 
 
 def _case(name):
-    shape, p, D, H, L, B, T = SHAPES[name]
-    return make_case(shape, p, D, H, L, B, seed=41, clip_h=3.0, clip_w=0.5), T
+    gn = name.endswith("+gradnorm")         # use_vode_grad_norm: every leaf normalised by its WHOLE-batch norm
+    shape, p, D, H, L, B, T = SHAPES[name.split("+")[0]]
+    return make_case(shape, p, D, H, L, B, seed=41, clip_h=3.0, clip_w=0.5, use_grad_norm=gn, grad_norm_target=2.0), T
 
 
 def _worker(rank, world, port, name, exact, q):
@@ -120,3 +121,22 @@ def test_split_step_single_rank_matches_fused_step(name):
         assert np.abs(x - y).max() <= 1e-4 * np.abs(x).max()
     for k in wa:
         assert np.abs(wa[k] - wb[k]).max() <= 1e-4 * max(np.abs(wa[k]).max(), 1e-3), k
+
+
+@pytest.mark.parametrize("name", ["fused_shape+gradnorm", "general_h2+gradnorm"])
+def test_two_ranks_grad_norm_match_one_rank(name):
+    """`use_vode_grad_norm` (/root/reference/src/decoder_transformer.py:353-389) divides every leaf by its
+    whole-batch norm on every step, so DataParallel must run the batch-global sums even when the caller
+    asked for the local mode (it switches itself, with a warning): 2 ranks x B/2 == 1 rank x B."""
+    import cora_amd as ca
+    case, T = _case(name)
+    model, optim_w, optim_h = build_model(case)
+    ca.train_on_batch(T, case["x"], model=model, optim_w=optim_w, optim_h=optim_h)
+    L = model.L
+    h_ref = [model.vodes[l].h.get() for l in range(L + 2)]
+    model.close()
+    res = _run_sharded(name, exact=False)
+    for l in range(L + 2):
+        got = np.concatenate([res[0][1][l], res[1][1][l]], axis=0)
+        err = np.abs(got - h_ref[l]).max() / (np.abs(h_ref[l]).max() + 1e-30)
+        assert err <= 2e-5, f"vode {l}: sharded vs unsharded rel err {err}"

@@ -155,3 +155,85 @@ def test_train_epoch_and_pretext_metrics():
     assert m["full_mse"] > 0 and m["masked_mse"] > 0 and m["full_psnr"] == pytest.approx(
         np.mean([10 * np.log10(1.0 / max(v, 1e-8)) for v in [m["full_mse"]]]), abs=1.0)
     model.close(); model2.close()
+
+
+@pytest.mark.parametrize("name", ["fused_shape", "general_h2"])
+def test_grad_norm_option_in_inference_loops(name):
+    """`use_vode_grad_norm` in the two inference-only loops: unmask_on_batch_enhanced applies only the
+    layer scaling (:925-933, no normalize_vode_h_gradients call), the linear-probe extractor scales AND
+    normalises each leaf (/root/reference/examples/linear_probe.py:223-232).  With the option on the two
+    walk different trajectories from the same start; each must match its own oracle run."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = SHAPES[name]
+    case = make_case(shape, p, D, H, L, B, seed=24, clip_h=2.0, use_grad_norm=True, grad_norm_target=1.5)
+    model, optim_w, optim_h = build_model(case)
+    x = case["x"]
+    args = (T, x, x, None, case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T)
+    errs, floor = {}, {}
+    ref = R.unmask_on_batch(*args, use_corruption=False, normalise=False)
+    r32 = R.unmask_on_batch(*args, use_corruption=False, normalise=False, dtype=torch.float32)
+    loss, recons, _, log = ca.unmask_on_batch_enhanced(False, 0.0, [T], x, model=model, optim_h=optim_h,
+                                                       log_inference_grads=True)
+    _cmp(errs, floor, "unmask.loss", loss, ref["loss"], r32["loss"])
+    for l in range(L + 2):
+        _cmp(errs, floor, f"unmask.h{l}", model.vodes[l].h.get(), ref["h"][l], r32["h"][l])
+    got = [log[T - 1][f"vode_{i}_grad_norm"] for i in range(L + 2)]      # norms of the SCALED, un-normalised leaves
+    _cmp(errs, floor, "unmask.gnorm", got, ref["grad_norms"][T - 1][:L + 2], r32["grad_norms"][T - 1][:L + 2])
+    h_unmask = model.vodes[L + 1].h.get()
+    for l, t in enumerate(case["h"]):
+        model.vodes[l].h.set(t)
+    f = ca.extract_features_from_batch(x, model, optim_h, T, [1, -2], False)
+    refn = R.unmask_on_batch(*args, use_corruption=False, normalise=True)
+    r32n = R.unmask_on_batch(*args, use_corruption=False, normalise=True, dtype=torch.float32)
+    want = np.concatenate([refn["h"][1], refn["h"][L + 1]], axis=-1)
+    w32 = np.concatenate([r32n["h"][1], r32n["h"][L + 1]], axis=-1)
+    _cmp(errs, floor, "features", f, want, w32)
+    # the two loops really differ here, so a wrong flag cannot pass both comparisons
+    assert np.abs(refn["h"][L + 1] - ref["h"][L + 1]).max() > 1e-3 * np.abs(ref["h"][L + 1]).max()
+    assert np.abs(model.vodes[L + 1].h.get() - h_unmask).max() > 1e-3 * np.abs(h_unmask).max()
+    model.close()
+    _check(name, errs, floor)
+
+
+@pytest.mark.parametrize("name", ["fused_shape", "general_h2"])
+def test_unmask_update_weights_during_unmasking(name):
+    """`update_weights_during_unmasking` (:967-979): every vode step of the loop is followed by dE/dW at
+    the updated vodes and one clip + AdamW step scaled by 1 / x.shape[0], before the clamp.  Vodes,
+    reconstructions and loss to the fp32 bar; weights compared where the fp64 gradient is not
+    noise-sized, in units of the total AdamW move (see test_ipc_mode... in test_gpu_parity.py)."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = SHAPES[name]
+    case = make_case(shape, p, D, H, L, B, seed=25, clip_h=3.0)
+    model, optim_w, optim_h = build_model(case)
+    model.config.update_weights_during_unmasking = True
+    model.config.use_lower_half_mask = True
+    model.config.inference_clamp_alpha = 0.7
+    x = case["x"]
+    mask, x_init = ca.make_mask(model, x, 0.5)
+    args = (T, x, x_init, mask, case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T)
+    kw = dict(alpha=0.7, use_corruption=True, eta_w=[1e-3] * T)
+    ref = R.unmask_on_batch(*args, **kw)
+    r32 = R.unmask_on_batch(*args, dtype=torch.float32, **kw)
+    loss, recons, _, _ = ca.unmask_on_batch_enhanced(True, 0.5, [T], x, model=model, optim_h=optim_h, optim_w=optim_w)
+    assert optim_w.count == T and model.get_adam_state()[2] == T
+    errs, floor = {}, {}
+    for t in range(T):
+        _cmp(errs, floor, f"recon{t}", recons[t], ref["recons"][t], r32["recons"][t])
+    _cmp(errs, floor, "loss", loss, ref["loss"], r32["loss"])
+    for l in range(L + 2):
+        _cmp(errs, floor, f"h{l}", model.vodes[l].h.get(), ref["h"][l], r32["h"][l])
+    _cmp(errs, floor, "sensory", model.vodes[L + 2].h.get(), ref["sensory"], r32["sensory"])
+    neww = model.get_weights()
+    moved = 0
+    for k, v in ref["weights"].items():
+        step = np.abs(v - case["W"][k].astype(np.float64))
+        sel = step > 0.5 * T * 1e-3            # entries AdamW moved at (nearly) the full rate every step: gradient not noise-sized
+        if sel.any():
+            moved += int(sel.sum())
+            d = np.abs(neww[k].astype(np.float64) - v)[sel].max() / (T * 1e-3)
+            d32 = np.abs(r32["weights"][k].astype(np.float64) - v)[sel].max() / (T * 1e-3)
+            assert d <= max(2e-2, 3.0 * d32), (k, d, d32)
+        assert np.abs(neww[k] - case["W"][k]).max() > 0, k       # every tensor did move
+    assert moved > 100
+    model.close()
+    _check(name, errs, floor)

@@ -164,3 +164,77 @@ def test_make_mask_and_psnr():
     assert np.array_equal(xc[mb == 0], x[mb == 0]) and np.abs(xc[mb == 1]).max() < 1.0
     assert ca.calculate_psnr(x, x) == pytest.approx(80.0)            # epsilon floor: 10 log10(1 / 1e-8)
     assert ca.calculate_psnr(np.zeros(4), np.full(4, 0.1)) == pytest.approx(20.0)
+
+
+def _reference_key_set(L, vode_ln=False, vodes=True):
+    """The archive keys `pcx.utils.save_params(model, path, filter=LayerParam | VodeParam)` writes for the
+    reference's TransformerDecoder: `jtu.keystr` of the path to every selected Param
+    (/root/reference/pcx/utils/_serialisation.py:47-60).  Written out by hand from the reference's attribute
+    names -- TransformerDecoder.__init__ (/root/reference/src/decoder_transformer.py:140-218: `vodes`,
+    `transformer_blocks`, `patch_projection`, `output_projection`, `vode_output_layernorms`),
+    pxnn.TransformerBlock (/root/reference/pcx/nn/_layer.py:419-426: `layer_norm1/2`, `attention`,
+    `linear1/2`), Layer.nn (:53-58) and the equinox field names (`weight`, `bias`, `query_proj`, ...) --
+    so that it does not share code with cora_amd.params."""
+    keys = set()
+    for i in range(L):
+        b = ".transformer_blocks[%d]" % i
+        for ln in ("layer_norm1", "layer_norm2"):
+            keys |= {b + "." + ln + ".nn.weight", b + "." + ln + ".nn.bias"}
+        for pr in ("query_proj", "key_proj", "value_proj", "output_proj"):
+            keys.add(b + ".attention.nn." + pr + ".weight")           # use_*_bias=False: no bias leaves
+        for lin in ("linear1", "linear2"):
+            keys |= {b + "." + lin + ".nn.weight", b + "." + lin + ".nn.bias"}
+    for lin in ("patch_projection", "output_projection"):
+        keys |= {"." + lin + ".nn.weight", "." + lin + ".nn.bias"}
+    if vode_ln:
+        for i in range(L + 1):
+            keys |= {".vode_output_layernorms[%d].nn.weight" % i, ".vode_output_layernorms[%d].nn.bias" % i}
+    if vodes:
+        keys |= {".vodes[%d].h" % l for l in range(L + 3)}
+    return keys
+
+
+@pytest.mark.parametrize("vode_ln", [False, True])
+def test_npz_layer_param_keys_and_round_trip(tmp_path, vode_ln):
+    """save_params / load_params (pcx/utils/_serialisation.py:25-105) on the LayerParam tree, no GPU needed:
+    the key set is the reference's, an archive holding exactly those keys loads into a fresh model, a
+    missing key raises the reference's KeyError, class / union / predicate filters all work."""
+    L = 2
+    cfg = ca.create_config(hidden_size=16, num_heads=2, num_blocks=L, use_vode_state_layernorm=vode_ln)
+    m = ca.TransformerDecoder(cfg, seed=3)
+    path = str(tmp_path / "ckpt")
+    ca.save_params(m, path, filter=ca.LayerParam)                # np.savez_compressed appends .npz, as in the reference
+    want = _reference_key_set(L, vode_ln, vodes=False)
+    with np.load(path + ".npz") as z:
+        assert set(z.files) == want
+        assert z[".transformer_blocks[1].linear1.nn.weight"].shape == (64, 16)
+        assert z[".transformer_blocks[0].attention.nn.value_proj.weight"].dtype == np.float32
+    # an archive with exactly the reference's keys (written here with plain NumPy, not by save_params) loads
+    rng = np.random.default_rng(0)
+    shapes = dict(param_shapes(cfg.patch_dim, 16, 64, L, vode_ln))
+    blob = {k: rng.standard_normal(shapes[k]).astype(np.float32) for k in want}
+    np.savez_compressed(str(tmp_path / "ref_style"), **blob)
+    m2 = ca.TransformerDecoder(cfg, seed=99)
+    ca.load_params(m2, str(tmp_path / "ref_style"))              # '.npz' added like the reference (:87)
+    got = m2.get_weights()
+    for k in want:
+        np.testing.assert_array_equal(got[k], blob[k])
+    np.testing.assert_array_equal(m2.transformer_blocks[1].attention.nn.key_proj.weight.get(),
+                                  blob[".transformer_blocks[1].attention.nn.key_proj.weight"])
+    # predicate filter (the reference accepts Callable[[Any], bool], :28)
+    ca.save_params(m2, str(tmp_path / "pred"), filter=lambda p: isinstance(p, ca.LayerParam))
+    with np.load(str(tmp_path / "pred.npz")) as z:
+        assert set(z.files) == want
+    del blob[".output_projection.nn.bias"]
+    np.savez_compressed(str(tmp_path / "short"), **blob)
+    with pytest.raises(KeyError, match="not found in the file"):
+        ca.load_params(ca.TransformerDecoder(cfg), str(tmp_path / "short.npz"))
+    with pytest.raises(TypeError):
+        ca.save_params(m, path, filter=3)
+
+
+def test_optim_init_resets_schedule_count():
+    ow = ca.Optim(lambda: ca.chain(ca.clip_by_global_norm(1.0), ca.adamw(1e-3)))
+    ow.count = 7
+    ow.init()
+    assert ow.count == 0 and ow._recipe().base.weight_decay == 1e-4
