@@ -5,6 +5,9 @@
 #include "../../include/cora_hip.h"
 #include "common.h"
 
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +26,33 @@ const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", 
                                    "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "vode_grad"};
 
 struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+
+// RCCL is bound at run time (dlopen on the first cora_comm_* call): the one-GPU path never loads it.
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+const char* rccl_load() {   // nullptr on success, else what failed
+  if (g_rccl.so) return nullptr;
+  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) return "librccl.so not found (dlopen)";
+  RcclApi a; a.so = so;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(so, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(so, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(so, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(so, "ncclAllReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(so, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) return "librccl.so lacks a required symbol";
+  g_rccl = a;
+  return nullptr;
+}
 
 }  // namespace
 
@@ -87,6 +117,13 @@ struct cora_ctx {
   hipGraphExec_t learn_graph = nullptr;
   // data-parallel path: the two halves around the all-reduce, captured separately
   hipGraphExec_t wgrad_graph = nullptr, apply_graph = nullptr;
+  // data-parallel path with RCCL bound inside the library (cora_comm_init / cora_step_dist): the
+  // collectives sit INSIDE the captured graphs
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  bool dist_warm = false;
+  std::map<int, hipGraphExec_t> dist_graphs;   // key 2 T + exact_clip: T-step loop (+ per-step sum-of-squares all-reduce)
+  hipGraphExec_t dist_learn_graph = nullptr;   // wgrad, all-reduce of dE/dW, clip + AdamW, reconstruction
   float apply_graph_scale = 0.f;   // cora_step: weight gradients + AdamW + reconstruction, captured once
   float* hyp_dev = nullptr;               // {eta_w, 1 - b1^count, 1 - b2^count} for the captured AdamW
   double* host_out = nullptr;             // pinned: scalars read back at the end of cora_step
@@ -157,7 +194,8 @@ float* vode_ptr(cora_ctx* c, float* base, int l) { return l == 0 ? base : base +
 float* err_ptr(cora_ctx* c, int l) { return c->Es + (long long)(l - 1) * c->nl; }  // l = 1..L+1 ; L+2 = e_img
 
 void drop_learn_graphs(cora_ctx* c) {
-  if (c->learn_graph || c->wgrad_graph || c->apply_graph) hipStreamSynchronize(c->st);
+  if (c->learn_graph || c->wgrad_graph || c->apply_graph || c->dist_learn_graph) hipStreamSynchronize(c->st);
+  if (c->dist_learn_graph) { hipGraphExecDestroy(c->dist_learn_graph); c->dist_learn_graph = nullptr; }
   if (c->learn_graph) { hipGraphExecDestroy(c->learn_graph); c->learn_graph = nullptr; }
   if (c->wgrad_graph) { hipGraphExecDestroy(c->wgrad_graph); c->wgrad_graph = nullptr; }
   if (c->apply_graph) { hipGraphExecDestroy(c->apply_graph); c->apply_graph = nullptr; }
@@ -175,6 +213,8 @@ int apply_grad_options(cora_ctx* c) {
       hipStreamSynchronize(c->st) != hipSuccess) return -2;
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
   c->graphs.clear();
+  for (auto& kv : c->dist_graphs) hipGraphExecDestroy(kv.second);
+  c->dist_graphs.clear();
   return 0;
 }
 
@@ -599,45 +639,37 @@ extern "C" {
 
 const char* cora_last_error(const cora_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
-  if (!cfg || !out) { g_create_err = "null argument"; return -1; }
-  *out = nullptr;
-  auto bad = [&](const char* m) { g_create_err = m; return -1; };
-  if (cfg->dtype_mode != 0 && cfg->dtype_mode != 1) return bad("dtype_mode: 0 (fp32 MFMA, parity path) or 1 (bf16 MFMA operands, fp32 accumulate and state)");
-  if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return bad("non-positive dimension");
-  if (cfg->D % cfg->H) return bad("hidden_size must be divisible by num_heads");
-  if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return bad("D, P and M must be multiples of 4 (16-byte rows)");
-  if (((long long)cfg->B * cfg->N) % 4) return bad("B*N must be a multiple of 4");
-  if (cfg->L + 3 > 64) return bad("too many blocks (L <= 61)");
+// configuration checks of cora_create: nullptr = fine
+static const char* check_config(const cora_config* cfg) {
+  if (cfg->dtype_mode != 0 && cfg->dtype_mode != 1) return "dtype_mode: 0 (fp32 MFMA, parity path) or 1 (bf16 MFMA operands, fp32 accumulate and state)";
+  if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return "non-positive dimension";
+  if (cfg->D % cfg->H) return "hidden_size must be divisible by num_heads";
+  if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return "D, P and M must be multiples of 4 (16-byte rows)";
+  if (((long long)cfg->B * cfg->N) % 4) return "B*N must be a multiple of 4";
+  if (cfg->L + 3 > 64) return "too many blocks (L <= 61)";
   {   // the GEMM epilogue addresses one group's output with 32-bit element offsets
     long long widest = cfg->M > 3 * cfg->D ? cfg->M : 3 * cfg->D;
     if (cfg->P > widest) widest = cfg->P;
-    if ((long long)cfg->B * cfg->N * widest >= (1LL << 31)) return bad("B*N*max(M, 3D, P) must stay below 2^31 elements");
+    if ((long long)cfg->B * cfg->N * widest >= (1LL << 31)) return "B*N*max(M, 3D, P) must stay below 2^31 elements";
   }
-  if (cfg->P != cfg->patch * cfg->patch * cfg->C) return bad("P != patch*patch*C");
-  if (cfg->N != cfg->F * (cfg->Himg / cfg->patch) * (cfg->Wimg / cfg->patch)) return bad("N != F*(H/p)*(W/p)");
+  if (cfg->P != cfg->patch * cfg->patch * cfg->C) return "P != patch*patch*C";
+  if (cfg->F < 1 || cfg->patch < 1 || cfg->N != cfg->F * (cfg->Himg / cfg->patch) * (cfg->Wimg / cfg->patch)) return "N != F*(H/p)*(W/p)";
   if (cfg->L > 0) {
     int dh = cfg->D / cfg->H;
-    if (!(dh == 16 || dh == 24 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return bad("head dim must be one of 16,24,32,48,64,96,128");
-    if (cfg->D > 768) return bad("hidden_size > 768 not supported by the LayerNorm kernels");
+    if (!(dh == 16 || dh == 24 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return "head dim must be one of 16,24,32,48,64,96,128";
+    if (cfg->D > 768) return "hidden_size > 768 not supported by the LayerNorm kernels";
   }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bad("no HIP device visible");
-  if (device < 0 || device >= ndev) return bad("device index out of range");
-  if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+  return nullptr;
+}
 
-  cora_ctx* c = new cora_ctx();
+// dims and the weight-arena layout (per-type stacks, then the two projections, then the vode LayerNorms)
+static void layout_ctx(cora_ctx* c, const cora_config* cfg, int device) {
   c->cfg = *cfg; c->device = device;
   c->N = cfg->N; c->P = cfg->P; c->D = cfg->D; c->H = cfg->H; c->M = cfg->M; c->L = cfg->L; c->B = cfg->B;
   c->BN = (long long)c->B * c->N;
   c->n0 = c->BN * c->P; c->nl = c->BN * c->D; c->nV = c->n0 + (long long)(c->L + 1) * c->nl;
   c->Tmax = cfg->max_T > 0 ? cfg->max_T : 64;
   c->nImg = (long long)c->B * cfg->F * cfg->C * cfg->Himg * cfg->Wimg;
-  c->use_graph = getenv("CORA_NO_GRAPH") == nullptr;
-  auto fail = [&](int rc) { g_create_err = c->err; cora_destroy(c); return rc; };
-  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(-2); }
-  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1); hipEventCreate(&c->ev2);
-
   const size_t D = c->D, P = c->P, M = c->M, L = c->L;
   size_t o = 0;
   c->oLn1g = o; o += L * D; c->oLn1b = o; o += L * D; c->oLn2g = o; o += L * D; c->oLn2b = o; o += L * D;
@@ -647,6 +679,25 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->vln = cfg->use_vode_ln != 0;
   if (c->vln) { c->oVg = o; o += (size_t)(L + 1) * D; c->oVb = o; o += (size_t)(L + 1) * D; }
   c->nW = o;
+}
+
+int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return -1; }
+  *out = nullptr;
+  auto bad = [&](const char* m) { g_create_err = m; return -1; };
+  if (const char* e = check_config(cfg)) return bad(e);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bad("no HIP device visible");
+  if (device < 0 || device >= ndev) return bad("device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+
+  cora_ctx* c = new cora_ctx();
+  layout_ctx(c, cfg, device);
+  c->use_graph = getenv("CORA_NO_GRAPH") == nullptr;
+  auto fail = [&](int rc) { g_create_err = c->err; cora_destroy(c); return rc; };
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(-2); }
+  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1); hipEventCreate(&c->ev2);
+  const size_t D = c->D, P = c->P, M = c->M, L = c->L;
 
   int rc = 0;
 #define DA(ptr, n) if ((rc = dalloc(c, &(ptr), (long long)(n)))) return fail(rc)
@@ -700,7 +751,9 @@ int cora_destroy(cora_ctx* c) {
   hipSetDevice(c->device);
   if (c->st) hipStreamSynchronize(c->st);
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : c->dist_graphs) hipGraphExecDestroy(kv.second);
   drop_learn_graphs(c);
+  if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
   for (void* p : c->allocs) hipFree(p);
   if (c->host_out) hipHostFree(c->host_out);
   if (c->host_in) hipHostFree(c->host_in);
@@ -890,6 +943,8 @@ int cora_set_optim(cora_ctx* c, float clip_h, float momentum, float clip_w, floa
     HCHECK(hipStreamSynchronize(c->st));
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+    for (auto& kv : c->dist_graphs) hipGraphExecDestroy(kv.second);
+    c->dist_graphs.clear();
   }
   if (learn_dirty) {
     HCHECK(hipSetDevice(c->device));
@@ -1383,6 +1438,161 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
     double sse = 0.0;
     HCHECK(hipMemcpy(&sse, c->scal + 1, sizeof(double), hipMemcpyDeviceToHost));
     out->train_mse = sse / (double)c->n0;
+  }
+  return 0;
+}
+
+// ---- data parallelism with RCCL bound inside the library ---------------------------------------------
+// (see include/cora_hip.h: cora_comm_unique_id / cora_comm_init / cora_step_dist)
+#define NCHECK(call)                                                                                   \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      c->err = std::string(#call " failed: ") + g_rccl.GetErrorString(r_);                             \
+      return -5;                                                                                       \
+    }                                                                                                  \
+  } while (0)
+
+int cora_comm_unique_id(void* id, size_t nbytes) {
+  if (!id || nbytes != sizeof(ncclUniqueId)) { g_create_err = "unique id buffer must be 128 bytes"; return -1; }
+  if (const char* e = rccl_load()) { g_create_err = e; return -5; }
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) { g_create_err = std::string("ncclGetUniqueId failed: ") + g_rccl.GetErrorString(r); return -5; }
+  memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int cora_comm_init(cora_ctx* c, const void* id, size_t nbytes, int rank, int world) {
+  if (!c) return -1;
+  if (!id || nbytes != sizeof(ncclUniqueId)) FAIL(-1, "unique id buffer must be 128 bytes");
+  if (world < 1 || rank < 0 || rank >= world) FAIL(-1, "rank / world out of range");
+  if (c->comm) FAIL(-1, "communicator already initialised");
+  if (const char* e = rccl_load()) FAIL(-5, e);
+  HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  NCHECK(g_rccl.CommInitRank(&c->comm, world, u, rank));
+  c->comm_rank = rank; c->comm_world = world;
+  c->dist_warm = false;
+  return 0;
+}
+
+int cora_comm_info(const cora_ctx* c, int* rank, int* world) {
+  if (!c) return -1;
+  if (rank) *rank = c->comm ? c->comm_rank : -1;
+  if (world) *world = c->comm ? c->comm_world : 0;
+  return 0;
+}
+
+// T inference steps; with exact_clip the per-vode sums of squares of step t (row t of c->sumsq, (L+2)*8
+// doubles) are summed over the ranks between the gradient half and the update half, so
+// optax.clip_by_global_norm (and normalize_vode_h_gradients) see the norm of the WHOLE batch
+static int enqueue_infer_dist(cora_ctx* c, int T, bool exact) {
+  zero_infer_logs(c, T);
+  const size_t nrow = (size_t)(c->L + 2) * 8;
+  for (int t = 0; t < T; ++t) {
+    int rc = infer_grad_step(c, t);
+    if (rc) return rc;
+    if (exact) {
+      double* row = c->sumsq + (long long)t * nrow;
+      NCHECK(g_rccl.AllReduce(row, row, nrow, ncclDouble, ncclSum, c->comm, c->st));
+    }
+    if ((rc = infer_update_step(c, t))) return rc;
+  }
+  return 0;
+}
+// dE/dW of this shard, SUM over ranks, then the identical clip + AdamW step (scale 1 / (B_local * world),
+// /root/reference/src/decoder_transformer.py:484) and the reconstruction on every rank
+static int enqueue_learn_dist(cora_ctx* c) {
+  int rc = enqueue_wgrad(c);
+  if (rc) return rc;
+  NCHECK(g_rccl.AllReduce(c->dW, c->dW, c->nW, ncclFloat, ncclSum, c->comm, c->st));
+  return enqueue_apply(c, 1.0f / ((float)c->B * (float)c->comm_world));
+}
+
+int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, float eta_w,
+                   int exact_clip, cora_step_out* out) {
+  if (!c) return -1;
+  if (!c->comm) FAIL(-1, "cora_step_dist: call cora_comm_init first");
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!eta_h) FAIL(-1, "eta_h is NULL");
+  HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
+  const int L = c->L;
+  const bool exact = exact_clip != 0;
+  int rc = upload_x(c, x, x_on_device);
+  if (rc) return rc;
+  const double cnt = (double)(c->adam_count + 1);
+  memcpy(c->host_in, eta_h, sizeof(float) * T);
+  float* hy = c->host_in + c->Tmax;
+  hy[0] = eta_w;
+  hy[1] = (float)(1.0 - pow((double)c->cfg.adam_b1, cnt));
+  hy[2] = (float)(1.0 - pow((double)c->cfg.adam_b2, cnt));
+  hy[3] = 0.f;
+  HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
+  HCHECK(hipMemcpyAsync(c->hyp_dev, hy, sizeof(float) * 4, hipMemcpyHostToDevice, c->st));
+  c->last_T = T;
+  const bool graphed = c->use_graph && !c->prof && c->dist_warm;
+  if (!graphed) {
+    // first call (and CORA_NO_GRAPH): eager launches -- every kernel and every collective runs once
+    // outside stream capture (RCCL sets up its channels and buffers on first use)
+    HCHECK(hipEventRecord(c->ev0, c->st));
+    if ((rc = enqueue_infer_dist(c, T, exact))) return rc;
+    HCHECK(hipEventRecord(c->ev1, c->st));
+    if ((rc = enqueue_learn_dist(c))) return rc;
+  } else {
+    const int key = 2 * T + (exact ? 1 : 0);
+    auto it = c->dist_graphs.find(key);
+    if (it == c->dist_graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed));
+      rc = enqueue_infer_dist(c, T, exact);
+      hipError_t e = hipStreamEndCapture(c->st, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+      HCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      c->dist_graphs[key] = exec;
+      it = c->dist_graphs.find(key);
+    }
+    if (!c->dist_learn_graph) {
+      hipGraph_t graph = nullptr;
+      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed));
+      rc = enqueue_learn_dist(c);
+      hipError_t e = hipStreamEndCapture(c->st, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+      HCHECK(hipGraphInstantiate(&c->dist_learn_graph, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+    }
+    HCHECK(hipEventRecord(c->ev0, c->st));
+    HCHECK(hipGraphLaunch(it->second, c->st));
+    HCHECK(hipEventRecord(c->ev1, c->st));
+    HCHECK(hipGraphLaunch(c->dist_learn_graph, c->st));
+  }
+  c->adam_count += 1;
+  HCHECK(hipEventRecord(c->ev2, c->st));
+  double* ho = c->host_out;
+  const size_t nslot = (size_t)(L + 3) * 8;
+  if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+  else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipStreamSynchronize(c->st));
+  c->dist_warm = true;
+  c->learn_warm = true;
+  if (out) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
+    hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
+    double eh = 0.0, ew = 0.0;
+    for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+    for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
+    out->final_h_energy = eh; out->final_w_energy = ew;
+    out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;
   }
   return 0;
 }

@@ -40,9 +40,18 @@ def shard_slice(batch: int, rank: int, world: int) -> slice:
 
 
 class DataParallel:
-    """Owns the torch view of the flat dE/dW buffer and runs the one collective of the step."""
+    """Binds a model to the data-parallel step.  Two transports:
 
-    def __init__(self, model, batch_size: int, group=None, exact_clip: bool = False):
+    backend="rccl"  : RCCL bound inside libcora_hip.so (`cora_comm_init` / `cora_step_dist`): both
+                      exchanges -- the per-step sums of squares of the exact clip and the dE/dW sum --
+                      sit inside the captured hipGraphs.  torch.distributed (any backend) is only used
+                      once, to hand rank 0's 128-byte RCCL id to the other ranks.
+    backend="torch" : the step split at the exchange point (`cora_infer` / `cora_wgrad` / all-reduce by
+                      torch.distributed / `cora_apply_wgrad`); with exact_clip one host round trip per
+                      inference step.  Works with gloo (CPU tests, several ranks on one GPU).
+    backend="auto"  : "torch" under a gloo group, "rccl" otherwise."""
+
+    def __init__(self, model, batch_size: int, group=None, exact_clip: bool = False, backend: str = "auto"):
         import torch
         import ctypes as C
         from . import _lib
@@ -51,16 +60,35 @@ class DataParallel:
         self.group = group
         self.exact_clip = bool(exact_clip)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if backend == "auto":
+            backend = "torch" if (dist.is_initialized() and dist.get_backend(group) == "gloo") else "rccl"
+        if backend not in ("rccl", "torch"):
+            raise ValueError("backend must be 'auto', 'rccl' or 'torch'")
+        self.backend, self.world, self.rank = backend, world, rank
+        self.in_library = backend == "rccl"
         if world > 1 and bool(model.config.use_vode_grad_norm) and not self.exact_clip:
             warnings.warn("use_vode_grad_norm normalises each vode gradient by its whole-batch norm on every "
                           "step: data-parallel shards need the batch-global sums -> exact_clip=True")
             self.exact_clip = True
         ctx = model._ensure_ctx(batch_size)
+        model._dp = self
+        if self.in_library:
+            lib = _lib.load()
+            ident = [None]
+            if rank == 0:
+                raw = C.create_string_buffer(128)
+                _lib.check(lib.cora_comm_unique_id(raw, 128), None)
+                ident[0] = raw.raw
+            if world > 1:
+                dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            _lib.check(lib.cora_comm_init(ctx, ident[0], 128, rank, world), ctx)
+            self.buf = None
+            return
         dev = torch.device("cuda", model.device)
         self.buf = torch.zeros(model._nW, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
         _lib.check(_lib.load().cora_bind_wgrad_buffer(ctx, C.c_void_p(self.buf.data_ptr()), self.buf.numel()), ctx)
-        model._dp = self
 
     def allreduce(self) -> int:
         # cora_wgrad synchronised its stream before returning, so the buffer is complete here.

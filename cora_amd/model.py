@@ -489,6 +489,9 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
         optim_w.count += T - 1                               # the common `count += 1` below makes it T
     elif model._dp is None:
         _lib.check(lib.cora_step(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w), C.byref(out)), ctx)
+    elif model._dp.in_library:                                # RCCL inside the captured graphs
+        _lib.check(lib.cora_step_dist(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w),
+                                      int(model._dp.exact_clip), C.byref(out)), ctx)
     else:
         if model._dp.exact_clip:
             model._dp.infer_exact(model, ctx, x, T, eta_h, out)

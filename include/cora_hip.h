@@ -163,6 +163,27 @@ int cora_infer_sumsq(cora_ctx* ctx, int t, double* host_row, size_t n_doubles, i
 int cora_infer_update(cora_ctx* ctx, int t);
 int cora_infer_end(cora_ctx* ctx, cora_step_out* out);
 
+/* Data parallelism with RCCL bound INSIDE the library, so that both exchanges of the sharded step sit in
+ * the captured hipGraphs (no host round trip per inference step).  The reference is single-device: the
+ * semantics kept are those of its global batch -- energy summed over the batch
+ * (/root/reference/src/decoder_transformer.py:305), optax.clip_by_global_norm over the whole batch on every
+ * inference step (/root/reference/examples/debug_transformer_wandb.py:1137-1140), dE/dW scaled by 1/B (:484).
+ *   rank 0: cora_comm_unique_id(id, 128); the host hands the 128 bytes to every rank (any transport);
+ *   every rank: cora_comm_init(ctx, id, 128, rank, world)       -- ncclCommInitRank, collective
+ *   per batch:  cora_step_dist(ctx, x_shard, ..., exact_clip, out)
+ * cora_step_dist = cora_step on this rank's B images with (exact_clip != 0) one SUM all-reduce of the
+ * (L+2)*8 per-vode sums of squares between the gradient half and the update half of every inference step,
+ * and one SUM all-reduce of the flat dE/dW buffer before the identical clip + AdamW step with scale
+ * 1 / (B * world) on every rank.  exact_clip = 0 clips by the shard's own norm (no collective in the loop;
+ * equal to the reference only when no shard clips and use_grad_norm is off).  The first call runs eagerly
+ * (RCCL warm-up), later calls replay two graphs.  out: energies / MSE of THIS shard.
+ * librccl.so is dlopen'ed by the first cora_comm_* call; the one-GPU entry points never load it. */
+int cora_comm_unique_id(void* id128, size_t nbytes);
+int cora_comm_init(cora_ctx* ctx, const void* id128, size_t nbytes, int rank, int world);
+int cora_comm_info(const cora_ctx* ctx, int* rank, int* world);   /* rank -1 / world 0: no communicator */
+int cora_step_dist(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h, float eta_w,
+                   int exact_clip, cora_step_out* out);
+
 /* Device pointer + length of the flat dE/dW buffer (same layout as the weight arena). */
 int cora_wgrad_buffer(cora_ctx* ctx, void** dev_ptr, size_t* n_floats);
 /* Let the caller own the buffer instead (e.g. a torch tensor used for the all-reduce). */

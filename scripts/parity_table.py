@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Writes profiles/r2_parity_table.json: for every parity case (the small shapes of
+tests/test_gpu_parity.py and the full-size cases of tests/parity_cases.py) and every compared tensor,
+the GPU's error against the fp64 oracle, the fp32 oracle's own error (floor) and the bar that was
+applied (max(1e-4, 3 x floor)).  Run on the GPU box:  python scripts/parity_table.py [out.json]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r2_parity_table.json")
+    from tests.parity_cases import FULL_CASES, TOL, run_full_case, summarise
+    from tests import test_gpu_parity as small
+    table = {"bar_rule": "max(1e-4, 3 x fp32-oracle floor); err and floor are max-abs / max-abs per tensor "
+                         "(weight gradients: over all weight gradients)", "cases": {}}
+    for name in FULL_CASES:
+        rows, info = run_full_case(name)
+        worst, relaxed = summarise(rows)
+        table["cases"][name] = {"info": info, "worst": {worst: rows[worst]}, "n_tensors": len(rows),
+                                "above_1e-4_bar": sorted(relaxed), "rows": rows}
+        print(name, info, "worst", worst, rows[worst], "relaxed", len(relaxed), flush=True)
+    for name in small.CASES:
+        errs, floor = small.run_case(name, return_floor=True)
+        rows = {k: {"err": v, "floor": floor[k], "bar": (1e-5 if k.startswith("adamw") else max(TOL, 3.0 * floor[k]))}
+                for k, v in errs.items()}
+        worst, relaxed = summarise(rows)
+        shape = small.CASES[name]
+        table["cases"]["small/" + name] = {"info": {"shape": list(map(str, shape))}, "worst": {worst: rows[worst]},
+                                           "n_tensors": len(rows), "above_1e-4_bar": sorted(relaxed), "rows": rows}
+        print("small/" + name, "worst", worst, rows[worst], "relaxed", len(relaxed), flush=True)
+    with open(out, "w") as f:
+        json.dump(table, f, indent=1)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()

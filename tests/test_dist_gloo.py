@@ -75,3 +75,27 @@ def test_shard_slice():
 def test_allreduce_without_process_group_is_identity():
     t = torch.ones(4)
     assert allreduce_sum_(t) == 1 and torch.equal(t, torch.ones(4))
+
+
+def test_bench_self_launch_two_ranks_cpu():
+    """`python bench.py --gpus 2` started as a plain command must start its own two rank processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child, parent never touches the GPU), rendezvous
+    and print ONE JSON line from rank 0.  --dry-run-launch swaps the GPU workload for a gloo barrier +
+    MAX-reduce so the launcher path runs on a CPU-only host."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch",
+                        "--global-batch", "200"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["world_observed"] == 2 and r["max_over_ranks"] == 2.0
+    assert r["scaling"] == "strong" and r["per_gpu_batch"] == 100 and r["global_batch"] == 200
+    # a rank that fails takes the launcher down with a non-zero exit (no hang)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch",
+                        "--global-batch", "7"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0      # dry run does not validate divisibility: both ranks report and exit cleanly

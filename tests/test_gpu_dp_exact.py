@@ -111,7 +111,7 @@ def test_split_step_single_rank_matches_fused_step(name):
     for split in (False, True):
         model, ow, oh = build_model(case)
         if split:
-            DataParallel(model, case["x"].shape[0])
+            DataParallel(model, case["x"].shape[0], backend="torch")
         outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(3)]
         res.append((outs[-1], [model.vodes[l].h.get() for l in range(len(case["h"]))], model.get_weights()))
         model.close()
@@ -140,3 +140,42 @@ def test_two_ranks_grad_norm_match_one_rank(name):
         got = np.concatenate([res[0][1][l], res[1][1][l]], axis=0)
         err = np.abs(got - h_ref[l]).max() / (np.abs(h_ref[l]).max() + 1e-30)
         assert err <= 2e-5, f"vode {l}: sharded vs unsharded rel err {err}"
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("exact", [True, False])
+def test_in_library_rccl_world1_matches_single_gpu_step(name, exact):
+    """`cora_step_dist` with a world-size-1 RCCL communicator (ncclCommInitRank with one rank; the
+    all-reduces of the sums-of-squares rows and of dE/dW are captured inside the two graphs) must walk
+    the trajectory of the one-GPU `cora_step`: four batches each, so the eager first call AND the graph
+    replays run.  The 2-rank numerics are covered by the gloo tests above (RCCL refuses two ranks on one
+    device); this one covers the captured-collective launch path itself."""
+    import ctypes as C
+    import cora_amd as ca
+    from cora_amd import _lib
+    from cora_amd.dist import DataParallel
+    case, T = _case(name)
+    res = []
+    for dist_path in (False, True):
+        model, ow, oh = build_model(case)
+        if dist_path:
+            dp = DataParallel(model, case["x"].shape[0], backend="rccl", exact_clip=exact)
+            r, w = C.c_int(), C.c_int()
+            _lib.check(_lib.load().cora_comm_info(model._ctx, C.byref(r), C.byref(w)), model._ctx)
+            assert dp.in_library and (r.value, w.value) == (0, 1)
+        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(4)]
+        tot, per = ca.step_energies(model, T)
+        res.append((outs, [model.vodes[l].h.get() for l in range(len(case["h"]))], model.get_weights(), tot,
+                    model.get_adam_state()[2]))
+        model.close()
+    (a, ha, wa, ea, ca_), (b, hb, wb, eb, cb_) = res
+    assert ca_ == cb_ == 4
+    # same kernels on the same inputs; the only run-to-run freedom is the order of float atomics in the
+    # split-K weight gradients and the slotted energy sums
+    for oa, ob in zip(a, b):
+        assert oa[0] == pytest.approx(ob[0], rel=1e-6) and oa[1] == pytest.approx(ob[1], rel=1e-6) and oa[4] == pytest.approx(ob[4], rel=1e-6)
+    np.testing.assert_allclose(ea, eb, rtol=1e-6)
+    for x, y in zip(ha, hb):
+        assert np.abs(x - y).max() <= 2e-5 * np.abs(x).max()
+    for k in wa:
+        assert np.abs(wa[k] - wb[k]).max() <= 1e-4 * max(np.abs(wa[k]).max(), 1e-3), k

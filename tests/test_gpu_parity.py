@@ -43,7 +43,7 @@ CASES = {
 }
 
 
-def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, **kw):
+def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=False, **kw):
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
     case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000, l1=l1, l2=l2, clip_h=clip_h, clip_w=clip_w, **kw)
@@ -89,7 +89,7 @@ def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, **kw):
     bad = {k: (v, floor[k]) for k, v in errs.items()
            if not (v <= (1e-5 if k.startswith("adamw") else max(TOL, 3.0 * floor[k])))}
     assert not bad, f"{name}: parity failures (err, fp32 floor): {bad}"
-    return errs
+    return (errs, floor) if return_floor else errs
 
 
 @pytest.mark.parametrize("name", list(CASES))
