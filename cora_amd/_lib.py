@@ -70,6 +70,8 @@ SIGNATURES = {
     "cora_get_wgrad": (C.c_int, [_P, _P, _SZ]),
     "cora_get_energies": (C.c_int, [_P, C.c_int, _P, _P]),
     "cora_forward": (C.c_int, [_P, _P, _SZ]),
+    "cora_forward_static_floats": (_SZ, [C.POINTER(CoraConfig)]),
+    "cora_forward_static": (C.c_int, [C.POINTER(CoraConfig), C.c_int, _P, _SZ, _P, _P, _P, _P]),
     "cora_energy": (C.c_int, [_P, _P, _DP, _P, _P, _SZ]),
     "cora_unmask": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
     "cora_unmask_learn": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, C.c_float, _P, _P, _P, _P]),

@@ -56,6 +56,32 @@ const char* rccl_load() {   // nullptr on success, else what failed
 
 }  // namespace
 
+// ---- allocation-free entry point (cora_forward_static): its scratch lives in the code object ---------
+// 16 MiB per GPU, held from module load until the process ends.  In HOST code the array's name is only
+// a stand-in for the symbol, not a device address: the per-device address comes from
+// hipGetSymbolAddress (static_scratch_ptr) and only that pointer is ever handed to kernels.
+#define CORA_STATIC_SCRATCH_FLOATS (4u * 1024u * 1024u)
+static __device__ __align__(256) float scratch[CORA_STATIC_SCRATCH_FLOATS];
+static float* g_scratch_ptr[64] = {};      // per device, filled once with that device current
+// Device address of this GPU's copy of `scratch` (each GPU holds its own copy at its own address).
+// Must run with `device` current and outside stream capture: cora_create does it for its device, and
+// cora_forward_static does it on its first call on a device.
+static int static_scratch_ptr(int device, float** out, std::string* err) {
+  if (device < 0 || device >= 64) { *err = "device index out of range"; return -1; }
+  if (!g_scratch_ptr[device]) {
+    float* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      *err = std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(e);
+      return -2;
+    }
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return 0;
+}
+
+
 struct cora_ctx {
   cora_config cfg;
   int device = 0;
@@ -639,7 +665,7 @@ extern "C" {
 
 const char* cora_last_error(const cora_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-// configuration checks of cora_create: nullptr = fine
+// configuration checks shared by cora_create and cora_forward_static: nullptr = fine
 static const char* check_config(const cora_config* cfg) {
   if (cfg->dtype_mode != 0 && cfg->dtype_mode != 1) return "dtype_mode: 0 (fp32 MFMA, parity path) or 1 (bf16 MFMA operands, fp32 accumulate and state)";
   if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return "non-positive dimension";
@@ -736,6 +762,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     return fail(-2);
 #undef DA
   if (apply_grad_options(c)) { c->err = "initial upload failed"; return fail(-2); }
+  { float* sp = nullptr; if (int rc2 = static_scratch_ptr(device, &sp, &c->err)) return fail(rc2); }
   // Launch every kernel of the inference step once outside stream capture (code-object load,
   // dynamic-LDS attributes).  All state is zero and eta = 0, so nothing observable changes.
   rc = enqueue_infer(c, 1);
@@ -1648,6 +1675,53 @@ int cora_forward(cora_ctx* c, float* xhat, size_t n) {
   int rc = chain_forward(c, false);
   if (rc) return rc;
   return download_image(c, c->z, xhat, n);
+}
+
+size_t cora_forward_static_floats(const cora_config* cfg) {
+  if (!cfg) return 0;
+  const size_t R = (size_t)cfg->B * cfg->N, D = cfg->D, M = cfg->M, P = cfg->P, H = cfg->H, L = cfg->L;
+  auto up = [](size_t n) { return (n + 63) / 64 * 64; };     // every region starts on a 256-byte boundary
+  size_t n = up(R * D) * 6 /* xn1 att y xn2 ua ub */ + up(R * 3 * D) + up(R * M) + up(R * P) + 2 * up(R * 2) + up(R * H);
+  if (cfg->use_vode_ln) n += up((L + 1) * R * D) + up(2 * (L + 1) * R);
+  return n;
+}
+
+int cora_forward_static(const cora_config* cfg, int device, const float* W_dev, size_t n_weights, const float* pos_dev,
+                        const float* h0_dev, float* xhat_dev, void* hip_stream) {
+  auto bad = [&](int rc, const std::string& m) { g_create_err = "cora_forward_static: " + m; return rc; };
+  if (!cfg || !W_dev || !pos_dev || !h0_dev || !xhat_dev) return bad(-1, "null argument");
+  if (const char* e = check_config(cfg)) return bad(-1, e);
+  const size_t need = cora_forward_static_floats(cfg);
+  if (need > (size_t)CORA_STATIC_SCRATCH_FLOATS) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "needs %zu floats of scratch, the static buffer holds %u (16 MiB): lower B (rows = B*N = %lld)",
+             need, (unsigned)CORA_STATIC_SCRATCH_FLOATS, (long long)cfg->B * cfg->N);
+    return bad(-6, buf);
+  }
+  if (hipSetDevice(device) != hipSuccess) return bad(-2, "hipSetDevice failed");
+  float* base = nullptr;
+  std::string err;
+  if (int rc = static_scratch_ptr(device, &base, &err)) return bad(rc, err);
+  // A host-side view of the problem: the same launch code as cora_forward, every pointer either the
+  // caller's or carved from this GPU's scratch.  Nothing is allocated, copied or synchronised.
+  cora_ctx v;
+  layout_ctx(&v, cfg, device);
+  if (n_weights != v.nW) return bad(-1, "weight arena size mismatch (see cora_weights_size)");
+  v.st = (hipStream_t)hip_stream;
+  v.W = const_cast<float*>(W_dev); v.pos = const_cast<float*>(pos_dev); v.Hs = const_cast<float*>(h0_dev);
+  v.fused = false; v.prof = false; v.Gmax = 1;
+  const size_t R = (size_t)v.BN, D = v.D;
+  size_t o = 0;
+  auto take = [&](size_t n) { float* q = base + o; o += (n + 63) / 64 * 64; return q; };
+  v.xn1 = take(R * D); v.att = take(R * D); v.y = take(R * D); v.xn2 = take(R * D); v.ua = take(R * D); v.ub = take(R * D);
+  v.qkv = take(R * 3 * D); v.a = take(R * v.M); v.z = take(R * v.P); v.st1 = take(R * 2); v.st2 = take(R * 2); v.lse = take(R * v.H);
+  if (v.vln) { v.hln = take((size_t)(v.L + 1) * R * D); v.stv = take(2 * (size_t)(v.L + 1) * R); }
+  int rc = chain_forward(&v, false);
+  if (rc) return bad(rc, v.err);
+  launch_patchify(xhat_dev, v.z, v.B, cfg->F, cfg->C, cfg->Himg, cfg->Wimg, cfg->patch, 1, v.st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return bad(-2, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return 0;
 }
 
 int cora_energy(cora_ctx* c, const float* x_host, double* E, double* per_layer, float* xhat, size_t n) {

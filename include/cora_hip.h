@@ -195,6 +195,23 @@ int cora_get_energies(cora_ctx* ctx, int T, double* total, double* per_layer);
 
 /* `forward(None, model=...)` under status "forward" (:488-489): xhat [B,C,H,W] to the host. */
 int cora_forward(cora_ctx* ctx, float* xhat_host, size_t n_floats);
+/* cora_forward without a ctx and WITHOUT ANY ALLOCATION -- no counterpart in the reference.  For callers
+ * that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The status-"forward" reconstruction (:488-489) of B images from their top latents:
+ *   W_dev   [n_weights]  flat weight arena on `device` (layout of cora_weight_offset / cora_get_weights)
+ *   pos_dev [N, D], h0_dev [B, N, P]  ->  xhat_dev [B, C, H, W]   (all device pointers, caller-owned)
+ * Every intermediate lives in a 16 MiB static __device__ array of the library (one copy per GPU, held
+ * until the process ends); cora_forward_static_floats(cfg) says how much of it a configuration needs and
+ * the call fails with a clear error above 4 Mi floats (cfg 2 shape: B <= 73).  Only kernel launches on
+ * `hip_stream` (a hipStream_t, NULL = the null stream): no hipMalloc / hipFree, no copies, no
+ * synchronisation.  The FIRST call on a device resolves the array's address (hipGetSymbolAddress) and so
+ * must not sit inside a stream capture unless a cora_create on that device came first.  All calls on one
+ * GPU share that GPU's array (it keeps the last call's contents; nothing in this path needs it zeroed):
+ * calls that overlap on one GPU race.  Errors: cora_last_error(NULL). */
+size_t cora_forward_static_floats(const cora_config* cfg);
+int cora_forward_static(const cora_config* cfg, int device, const float* W_dev, size_t n_weights,
+                        const float* pos_dev, const float* h0_dev, float* xhat_dev, void* hip_stream);
+
 /* `unmask_on_batch_enhanced` (/root/reference/src/decoder_transformer.py:833-1046): the inference-only /
  * inpainting loop.  x_true, x_init, mask: host [B,C,H,W] (mask already broadcast over channels,
  * 1 = masked; ignored unless use_corruption).  The sensory vode starts from x_init (:896-901); with
