@@ -78,6 +78,7 @@ SIGNATURES = {
     "cora_dbg_stamps": (C.c_int, [_P, _P, _SZ]),
     "cora_profile_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "cora_sync": (C.c_int, [_P]),
+    "cora_kernel_path": (C.c_int, [_P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -219,6 +219,12 @@ struct FusedP {
 };
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
 int launch_chain(const FusedP& p, int store_h, hipStream_t st);
+// wide variant (fused_wide.hip): N = 64, D = 96 / 128, inference step only; uses H1, E2, BP1, W, WT, S_stash, S_da
+bool fused_wide_supported(int N, int P, int D, int H, int M);
+int launch_fused_wide(const FusedP& p, int L, int D, hipStream_t st);
+// two workgroups per CU (fused_wide2.hip): D = 128, heads of 32; also uses S_dqkv as a dk | dv stash
+bool fused_wide2_supported(int N, int P, int D, int H, int M);
+int launch_fused_wide2(const FusedP& p, int L, hipStream_t st);
 void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
 size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

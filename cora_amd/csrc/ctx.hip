@@ -109,7 +109,10 @@ struct cora_ctx {
   float* pos = nullptr;
   float* WT = nullptr;      // transposed copies for the fused kernel's backward GEMMs
   size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, tWp = 0, tWout = 0, nWT = 0;
-  bool fused = false;
+  bool fused = false;     // D = 64 fused kernel (inference, STORE and chain modes)
+  bool fusedw = false;    // D = 96 / 128 fused kernel (inference step only; learning phase and chain stay per-op)
+  bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
+  bool slotted() const { return fused || fusedw; }   // inference-step energies kept as 8 partial sums per vode (esum)
 
   // vodes
   float *Hs = nullptr, *Ms = nullptr, *Gs = nullptr, *Es = nullptr;  // Es: e_1..e_{L+1} then e_img
@@ -398,7 +401,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
 
 // transposed weight copies (W^T) read by the fused kernel's backward GEMMs
 void refresh_wt(cora_ctx* c) {
-  if (!c->fused) return;
+  if (!c->fused && !c->fusedw) return;
   const int D = c->D, M = c->M, L = c->L;
   KScope s(c, K_OTHER, 0, 8.0 * c->nWT);
   TransposeSet t; memset(&t, 0, sizeof t);
@@ -419,7 +422,7 @@ double block_step_flops(cora_ctx* c) {
 // keep 8 partial sums per vode (no same-address atomics in the hot kernels); they are folded here.
 int energy_row(cora_ctx* c, int slot, double* en) {
   const int L = c->L;
-  if (c->fused && slot < c->Tmax) {
+  if (c->slotted() && slot < c->Tmax) {
     std::vector<double> s8((size_t)(L + 3) * 8);
     if (hipMemcpy(s8.data(), c->esum + (long long)slot * (L + 3) * 8, sizeof(double) * s8.size(), hipMemcpyDeviceToHost) != hipSuccess) return -2;
     for (int v = 0; v < L + 3; ++v) {
@@ -498,11 +501,39 @@ int infer_grad_step(cora_ctx* c, int t) {
     v.sumsq = ss + 8; v.esum = es + 8;
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
     launch_vode_grad(v, c->st);
+  } else if (c->fusedw) {
+    // wide fused kernel (D = 96 / 128): the two edge layers as four small GEMMs, then one launch for all L
+    // blocks (e_2..e_{L+1} and J^T e for vodes 1..L), then vode_grad as on the D = 64 path
+    double* es = c->esum + (long long)t * (L + 3) * 8;
+    patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), nullptr);   // e_1 (its energy comes from vode_grad)
+    out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, es + (long long)(L + 2) * 8);   // e_img + sensory energy
+    GemmP p = gemm_base(c, 1);       // g_0 = -s_0 e_1 Wp
+    p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
+    p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
+    p.mode = OUT_GRAD; p.alpha2 = c->scale_l[0]; p.red = ss + 0;
+    run_gemm(c, p, false, true);
+    p = gemm_base(c, 1);             // J^T e for vode L+1 = e_img Wout
+    p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
+    p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
+    p.mode = OUT_STORE;
+    run_gemm(c, p, false, true);
+    FusedP f;
+    fill_fused(c, f, nullptr, ss);
+    {
+      KScope s(c, K_FUSED, block_step_flops(c), 4.0 * 4 * L * c->nl);
+      if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
+    }
+    VodeGradP v; memset(&v, 0, sizeof v);
+    v.bp = vode_ptr(c, c->Gs, 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hs, 1); v.g = vode_ptr(c, c->Gs, 1);
+    v.gscale = c->gscale; v.nl = c->nl; v.nlay = L + 1; v.l1 = c->cfg.l1; v.l2 = c->cfg.l2;
+    v.sumsq = ss + 8; v.esum = es + 8;
+    KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
+    launch_vode_grad(v, c->st);
   } else {
     int rc0 = errors_pass(c, t);
     if (rc0) return rc0;
   }
-  if (!c->fused) {
+  if (!c->fused && !c->fusedw) {
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c, 1);
   p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
@@ -547,7 +578,7 @@ int infer_update_step(cora_ctx* c, int t) {
   u.sumsq = ss; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
   u.use_grad_norm = c->cfg.use_grad_norm; u.grad_norm_target = c->cfg.grad_norm_target;
   if (c->sens_live) {   // un-frozen sensory vode: one more leaf in the clip norm, then its own update
-    if (c->fused) { u.sens_e = c->esum + ((long long)t * (L + 3) + (L + 2)) * 8; u.sens_n = 8; }
+    if (c->slotted()) { u.sens_e = c->esum + ((long long)t * (L + 3) + (L + 2)) * 8; u.sens_n = 8; }
     else { u.sens_e = c->energies + (long long)t * (L + 3) + (L + 2); u.sens_n = 1; }
     u.sens_s = c->sens_scale;
   }
@@ -571,7 +602,7 @@ void zero_infer_logs(cora_ctx* c, int T) {
   const int L = c->L;
   launch_zero(c->energies, ((sizeof(double) * (size_t)T * (L + 3)) + 15) / 16 * 16, c->st);
   launch_zero(c->sumsq, sizeof(double) * (size_t)T * (L + 2) * 8, c->st);
-  if (c->fused) launch_zero(c->esum, sizeof(double) * (size_t)T * (L + 3) * 8, c->st);
+  if (c->slotted()) launch_zero(c->esum, sizeof(double) * (size_t)T * (L + 3) * 8, c->st);
   launch_zero(c->Ms, sizeof(float) * (size_t)c->nV, c->st);   // optim_h.init, :414
 }
 
@@ -730,13 +761,16 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->W, c->nW); DA(c->dW, c->nW); DA(c->amu, c->nW); DA(c->anu, c->nW);
   DA(c->pos, (long long)c->N * D);
   c->fused = (c->N == 64 && c->D == 64 && (c->H == 1 || c->H == 2 || c->H == 4) && c->M == 256 && c->P == 48 && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && getenv("CORA_NO_FUSED") == nullptr);
-  if (c->fused) {
+  c->fusedw = (!c->fused && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_wide_supported(c->N, c->P, c->D, c->H, c->M) &&
+               getenv("CORA_NO_FUSED") == nullptr);
+  c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
+  if (c->fused || c->fusedw) {
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
     c->nWT = t;
     DA(c->WT, c->nWT);
-    DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
+    if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
@@ -750,6 +784,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   DA(c->dqkv, rows * 3 * D); DA(c->dxn, rows * D);
   DA(c->ua, c->nl); DA(c->ub, c->nl); DA(c->z, c->n0);
   if (c->fused) DA(c->stash, rows * c->H * D);
+  if (c->fusedw) DA(c->stash, rows * (c->H * 64 + 3 * D));   // per token row: one 64-key row of P per head, then q (| k | v: two-workgroup form)
   DA(c->gscale, 64); DA(c->eta_dev, c->Tmax + 1);
   float* tmp = nullptr;
   DA(tmp, 2LL * (c->Tmax + 2) * (L + 3)); c->energies = (double*)tmp;
@@ -812,6 +847,8 @@ extern "C" int cora_dbg_stamps(cora_ctx* c, unsigned long long* host, size_t n) 
   }
   return 0;
 }
+
+int cora_kernel_path(const cora_ctx* c) { return c ? (c->fused ? 1 : (c->fusedw ? 2 : 0)) : -1; }
 
 int cora_sync(cora_ctx* c) {
   if (!c) return -1;
@@ -1190,7 +1227,7 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
     const int T = c->last_T;
     double* ho = c->host_out;
     const size_t nslot = (size_t)(L + 3) * 8;
-    if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+    if (c->slotted()) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
     else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
     HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)slot * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
     HCHECK(hipStreamSynchronize(c->st));
@@ -1199,7 +1236,7 @@ int cora_wgrad(cora_ctx* c, cora_step_out* out) {
       hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
       hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
       double eh = 0.0, ew = 0.0;
-      for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+      for (size_t k = 0; k < (c->slotted() ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
       for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
       out->final_h_energy = eh; out->final_w_energy = ew;
     }
@@ -1336,7 +1373,7 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   // scalars back through pinned memory: [energy row of step T-1 (slots or plain)] [w-energy row] [mse sum]
   double* ho = c->host_out;
   const size_t nslot = (size_t)(L + 3) * 8;
-  if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+  if (c->slotted()) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
   else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
   HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
   HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -1346,7 +1383,7 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
     hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
     hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
     double eh = 0.0, ew = 0.0;
-    for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+    for (size_t k = 0; k < (c->slotted() ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
     for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
     out->final_h_energy = eh; out->final_w_energy = ew;
     out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;
@@ -1604,7 +1641,7 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
   HCHECK(hipEventRecord(c->ev2, c->st));
   double* ho = c->host_out;
   const size_t nslot = (size_t)(L + 3) * 8;
-  if (c->fused) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
+  if (c->slotted()) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
   else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
   HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
   HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
@@ -1616,7 +1653,7 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
     hipEventElapsedTime(&ms, c->ev0, c->ev1); out->infer_ms = ms;
     hipEventElapsedTime(&ms, c->ev1, c->ev2); out->learn_ms = ms;
     double eh = 0.0, ew = 0.0;
-    for (size_t k = 0; k < (c->fused ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
+    for (size_t k = 0; k < (c->slotted() ? nslot : (size_t)(L + 3)); ++k) eh += ho[k];
     for (int k = 0; k < L + 3; ++k) ew += ho[nslot + k];
     out->final_h_energy = eh; out->final_w_energy = ew;
     out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;

@@ -1,0 +1,514 @@
+// fused_wide2.hip -- the fused per-(block, image) kernel for the canonical 12-block sweep point
+// (N = 64 tokens, D = 128, heads of 32: /root/reference/sweeps/sweep_12block_comprehensive.yaml:8-47),
+// built for TWO workgroups per CU.
+//
+// Same math and the same data layout "T" as fused_wide.hip (block /root/reference/pcx/nn/_layer.py:428-447,
+// attention :359-402, LayerNorm :296-315, double residual /root/reference/src/decoder_transformer.py:238,
+// hand-derived VJP of jax.value_and_grad(energy) w.r.t. the vodes, :396,445).  Why a second kernel: on
+// gfx950 one wave per SIMD cannot overlap its own non-matrix instructions with its v_mfma_f32_16x16x4_f32
+// stream -- measured (scripts/ubench/mfma_rate.hip) 32.3 cycles per MFMA bare, 34.9 with one ds_read_b128
+// per 4 MFMAs, +5.5 cycles per VALU instruction in between -- so fused_wide.hip (one workgroup per CU,
+// 141 KB of LDS, 512 registers) stalls at 40 cycles per MFMA in its GEMM stages.  Two waves per SIMD hide
+// each other's LDS / VALU / global issue.  To fit two workgroups on a CU (<= 80 KB LDS, <= 256 VGPRs):
+//  * weight tiles are D/4 = 32 output rows x D inputs (16.9 KB), two LDS slots, 96 tiles per workgroup;
+//    stage k writes tile k+1 to LDS, fetches tile k+2 into the 4 staging float4 and multiplies with tile k,
+//    the three interleaved group by group;
+//  * K / V / Q / dO never sit in LDS whole: attention runs head by head on compact [64 tokens][32 + 4]
+//    tiles (4 x 9.2 KB) that each wave fills with its own rows' slice of the head; q, k, v (and P, and
+//    gelu'(a)) wait for the backward in an L2-resident stash instead of LDS / registers;
+//  * 76.8 KB of LDS per workgroup: 2 weight slots 33.8 KB, 4 head tiles 36.9 KB, LSE / delta rows 2 KB,
+//    parameter block (b1, LN2 gamma / beta, b2, LN1 gamma) 4 KB.
+#include "common.h"
+
+#include "fused_wide_common.h"
+
+namespace {
+
+// acc[ot] (ot < 4: the 64 rows of a head tile) += sum over the head's NCH column groups of T[16 ot + i][c] xs[c]
+template <int LDH, int NCH>
+__device__ __forceinline__ void gemm_hd(const float* __restrict__ t, const float* xs, f32x4* acc, int i, int grp) {
+  const lds_float* tl = opaque(t + i * LDH + 4 * grp);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    float4 a[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) a[ot] = lds_ld4(&tl[16 * ot * LDH + 16 * c]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].x, xs[4 * c + 0], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].y, xs[4 * c + 1], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].z, xs[4 * c + 2], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].w, xs[4 * c + 3], acc[ot]);
+  }
+}
+// out[4 c + reg'] = scale * sum over the 64 tile rows j of T[j][16 c + 4 grp + reg'] * pf[j]
+template <int LDH, int NCH>
+__device__ __forceinline__ void accum_hd(const float* __restrict__ t, const float* pf, float* out, float scale, int i, int grp) {
+  f32x4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const lds_float* tl = opaque(t + 4 * grp * LDH + i);
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const lds_float* row = &tl[(16 * tt + reg) * LDH];
+      const float b = pf[4 * tt + reg];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = mfma16(row[16 * c], b, acc[c]);
+    }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[4 * c + reg] = acc[c][reg] * scale;
+}
+// this wave's rows of a head slice (NCH column groups, 4 NCH registers) -> its rows of a head tile
+template <int LDH, int NCH>
+__device__ __forceinline__ void put_slice(const float* xs, float* tile, int w, int i, int grp) {
+  lds_float* d = opaque_w(tile + (16 * w + i) * LDH + 4 * grp);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) lds_st4(d + 16 * c, make_float4(xs[4 * c], xs[4 * c + 1], xs[4 * c + 2], xs[4 * c + 3]));
+}
+template <int NCH>
+__device__ __forceinline__ void load_slice(float* f, const float* base, int grp) {   // base = row pointer + 16 * first column group
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(base + 16 * c + 4 * grp);
+    f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void store_slice(const float* f, float* base, int grp) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    *reinterpret_cast<float4*>(base + 16 * c + 4 * grp) = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
+}
+
+}  // namespace
+
+#ifdef CORA_STAMPS
+#define W2STAMP(K)                                                                                 \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (p.dbg) {                                                                                   \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                 \
+      if (threadIdx.x == 0) p.dbg[(long long)blockIdx.x * 16 + (K)] = t_;                          \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define W2STAMP(K) do {} while (0)
+#endif
+
+template <int NCT, int H>
+__device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, int g, int b) {
+  constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
+  constexpr int NOT = 2, TR = 32;                 // weight tile: 32 output rows x D inputs
+  constexpr int NQ = D / TR;                      // tiles per D outputs (4)
+  constexpr int LD = D + 4, SLOT = TR * LD;
+  constexpr int NST = TR * D / 4 / 256;           // staged float4 per thread and tile (4)
+  constexpr int DH = D / H, NCH = DH / 16, RH = 4 * NCH;   // head dim 32: 2 column groups, 8 registers per slice
+  constexpr int LDH = DH + 4, HT = 64 * LDH;      // head tile [64][36]
+  constexpr int NT = 24 * NQ;                     // 96 tiles
+  static_assert(DH == 32 && TR * D % 1024 == 0 && NST * 2 <= NCT, "built for heads of 32");
+  const float qscale = rsqrtf((float)DH);
+  const float sc = qscale * CORA_LOG2E;
+
+  float* wbuf = lds;                     // 2 weight slots
+  float* tA = lds + 2 * SLOT;            // head tiles: forward K_h V_h K_h' V_h' ; backward K_h V_h Q_h dO_h
+  float* tB = tA + HT;
+  float* tC = tB + HT;
+  float* tD = tC + HT;
+  float* rowc = tD + HT;                 // lse2[H][64], delta[H][64]
+  float* pb = rowc + 2 * H * 64;         // [b1 M | ln2 gamma D | ln2 beta D | b2 D | ln1 gamma D]
+  constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D, PB_LN1G = M + 3 * D;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  const long long nl = (long long)p.B * 64 * D;
+  const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;
+  const long long voff = (long long)g * nl + rowoff;
+  const float* xrow = p.H1 + voff;
+  const float* hnext = p.H1 + voff + nl;
+  const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;
+  float* st_p = p.S_stash + srow_g * (H * 64 + 3 * D);   // per token row: P (64 keys per head) | q | k | v
+  float* st_q = st_p + H * 64;
+  float* st_k = st_q + D;
+  float* st_v = st_k + D;
+  float* st_a = p.S_da + srow_g * M;                     // gelu'(a)
+  float* st_dkv = p.S_dqkv + srow_g * 3 * D;             // dk | dv between the attention backward and the last GEMM
+
+  const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
+  const float* Wo = p.W + p.oWo + (long long)g * D * D;
+  const float* W1 = p.W + p.oW1 + (long long)g * M * D;
+  const float* W2 = p.W + p.oW2 + (long long)g * D * M;
+  const float* W2T = p.WT + p.tW2 + (long long)g * M * D;          // [M][D]
+  const float* W1T = p.WT + p.tW1 + (long long)g * D * M;          // [D][M]
+  const float* WoT = p.WT + p.tWo + (long long)g * D * D;          // [D][D]
+  const float* WqkvT = p.WT + p.tWqkv + (long long)g * D * 3 * D;  // [D][3D]
+  const float* ln1g = p.W + p.oLn1g + (long long)g * D;
+  const float* ln1b = p.W + p.oLn1b + (long long)g * D;
+  {
+    constexpr int NP4 = (M + 4 * D) / 4;
+    for (int f = tid; f < NP4; f += 256) {
+      const int o = 4 * f;
+      const float* src = o < M ? p.W + p.ob1 + (long long)g * M + o
+                       : o < M + D ? p.W + p.oLn2g + (long long)g * D + (o - M)
+                       : o < M + 2 * D ? p.W + p.oLn2b + (long long)g * D + (o - M - D)
+                       : o < M + 3 * D ? p.W + p.ob2 + (long long)g * D + (o - M - 2 * D)
+                                       : ln1g + (o - M - 3 * D);
+      *reinterpret_cast<float4*>(pb + o) = *reinterpret_cast<const float4*>(src);   // visible after the first tile barrier
+    }
+  }
+
+  // ---- weight tile pipeline (see fused_wide.hip) ---------------------------------------------------------
+  // float4 #f of a tile = row f / (D/4), 16-byte column f % (D/4); thread t stages #t + 256 J: row
+  // t / 32 + 8 J, so piece J sits 8 rows further in both images: a scalar base per piece plus one
+  // per-thread offset per tile (global), immediates (LDS).
+  auto tile_src = [&](int k, int& ldw) -> const float* {
+    // forward: 0-11 Wqkv | 12-15 Wo | 16-47 MLP (per hidden chunk mt: 4 x W1 rows, 4 x W2 output quarters)
+    // backward: 48-79 MLP (4 x W2^T rows, 4 x W1^T quarters per chunk) | 80-83 Wo^T | 84-95 Wqkv^T (dq, dk, dv x 4 quarters)
+    if (k < 3 * NQ) { ldw = D; return Wqkv + (long long)k * TR * D; }
+    if (k < 4 * NQ) { ldw = D; return Wo + (long long)(k - 3 * NQ) * TR * D; }
+    if (k < 12 * NQ) {
+      const int mt = (k - 4 * NQ) / (2 * NQ), j = (k - 4 * NQ) % (2 * NQ);
+      if (j < NQ) { ldw = D; return W1 + ((long long)mt * D + j * TR) * D; }
+      ldw = M; return W2 + (long long)(j - NQ) * TR * M + (long long)mt * D;
+    }
+    if (k < 20 * NQ) {
+      const int mt = (k - 12 * NQ) / (2 * NQ), j = (k - 12 * NQ) % (2 * NQ);
+      if (j < NQ) { ldw = D; return W2T + ((long long)mt * D + j * TR) * D; }
+      ldw = M; return W1T + (long long)(j - NQ) * TR * M + (long long)mt * D;
+    }
+    if (k < 21 * NQ) { ldw = D; return WoT + (long long)(k - 20 * NQ) * TR * D; }
+    const int j = k - 21 * NQ;
+    ldw = 3 * D; return WqkvT + (long long)(j % NQ) * TR * 3 * D + (long long)(j / NQ) * D;
+  };
+  const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
+  float4 sr0, sr1, sr2, sr3;
+#define PF_ONE(J, REG, SRC, LDW) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
+#define PB_ONE(J, REG, WB) lds_st4((WB) + 8 * (J) * LD, REG);
+#define PREFETCH_ALL(K)                                                                           \
+  do {                                                                                            \
+    int ld_; const float* s_ = tile_src((K), ld_);                                                \
+    PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
+  } while (0)
+#define WRITE_ALL(S)                                                                              \
+  do {                                                                                            \
+    lds_float* wb_ = opaque_w(wbuf + (S) * SLOT + trow * LD + tcol);                              \
+    PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
+  } while (0)
+  // column group C of the multiplication with tile k; the even groups carry one staged float4 each
+#define GEMM_CT(C, XF, ACC)                                                                       \
+  {                                                                                               \
+    if ((C) + 1 < NCT) {                                                                          \
+      _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot)                                          \
+        a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
+    if ((C) == 0) { if (do_w_) { PB_ONE(0, sr0, wb_) } if (do_p_) { PF_ONE(0, sr0, ns_, nld_) } } \
+    if ((C) == 2) { if (do_w_) { PB_ONE(1, sr1, wb_) } if (do_p_) { PF_ONE(1, sr1, ns_, nld_) } } \
+    if ((C) == 4) { if (do_w_) { PB_ONE(2, sr2, wb_) } if (do_p_) { PF_ONE(2, sr2, ns_, nld_) } } \
+    if ((C) == 6) { if (do_w_) { PB_ONE(3, sr3, wb_) } if (do_p_) { PF_ONE(3, sr3, ns_, nld_) } } \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].w, (XF)[4 * (C) + 3], (ACC)[ot]); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+  int slot = 0;
+#define STAGE(K, XF, ACC)                                                                         \
+  do {                                                                                            \
+    const int k_ = (K);                                                                           \
+    const bool do_w_ = (k_ + 1 < NT);                                                             \
+    const bool do_p_ = (k_ + 2 < NT);                                                             \
+    int nld_ = D; const float* ns_ = do_p_ ? tile_src(k_ + 2, nld_) : nullptr;                    \
+    __syncthreads();                                                                              \
+    const lds_float* tl_ = opaque(wbuf + slot * SLOT + i * LD + 4 * grp);                         \
+    lds_float* wb_ = opaque_w(wbuf + (slot ^ 1) * SLOT + trow * LD + tcol);                       \
+    float4 a_[2][NOT];                                                                            \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
+    GEMM_CT(0, XF, ACC) GEMM_CT(1, XF, ACC) GEMM_CT(2, XF, ACC) GEMM_CT(3, XF, ACC)               \
+    GEMM_CT(4, XF, ACC) GEMM_CT(5, XF, ACC) GEMM_CT(6, XF, ACC) GEMM_CT(7, XF, ACC)               \
+    slot ^= 1;                                                                                    \
+    (void)wb_; (void)ns_; (void)nld_;                                                             \
+  } while (0)
+  static_assert(NCT == 8, "GEMM_CT is written out for 8 column groups");
+  // one GEMM with D outputs: NQ stages, quarter j -> registers [8 j, 8 j + 8) of OUT
+#define GEMM_D(K0, XF, OUT)                                                                       \
+  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) {                                             \
+    f32x4 acc_[NOT]; zero_acc<NOT>(acc_);                                                         \
+    STAGE((K0) + j_, XF, acc_);                                                                   \
+    unpack_at<NOT>(acc_, OUT, NOT * j_);                                                          \
+  }
+  // the same, accumulating into ACCD[NCT] over several K-chunks
+#define GEMM_D_ACC(K0, XF, ACCD)                                                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) STAGE((K0) + j_, XF, (ACCD) + NOT * j_);
+
+  PREFETCH_ALL(0);
+  WRITE_ALL(0);                    // tile 0 -> slot 0 (visible after stage 0's barrier)
+  PREFETCH_ALL(1);
+  W2STAMP(0);
+
+  // ---- forward ---------------------------------------------------------------------------------------
+  float y[R];
+  {
+    float q[R], kk[R], v[R];
+    {
+      float xin[R];
+      {
+        float x[R], gm[R], bt[R], xh[R + 1];
+        load_row<NCT>(x, xrow, grp);
+        load_row<NCT>(gm, ln1g, grp);
+        load_row<NCT>(bt, ln1b, grp);
+        ln_row<NCT>(x, gm, bt, xh, xin);
+      }
+      W2STAMP(1);
+      GEMM_D(0, xin, q)
+      GEMM_D(NQ, xin, kk)
+      GEMM_D(2 * NQ, xin, v)
+    }
+    store_row<NCT>(q, st_q, grp);       // q, k, v wait in the stash for the attention backward
+    store_row<NCT>(kk, st_k, grp);
+    store_row<NCT>(v, st_v, grp);
+    W2STAMP(2);
+    // attention, two heads per round: K_h, V_h slices of all 64 tokens in the head tiles
+    float of[R];
+#pragma unroll
+    for (int hp = 0; hp < H; hp += 2) {
+      __syncthreads();                   // the previous round's tiles are no longer read
+      put_slice<LDH, NCH>(kk + RH * hp, tA, w, i, grp);
+      put_slice<LDH, NCH>(v + RH * hp, tB, w, i, grp);
+      put_slice<LDH, NCH>(kk + RH * (hp + 1), tC, w, i, grp);
+      put_slice<LDH, NCH>(v + RH * (hp + 1), tD, w, i, grp);
+      __syncthreads();
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int h = hp + hh;
+        const float* tK = hh ? tC : tA;
+        const float* tV = hh ? tD : tB;
+        f32x4 sa[4];
+        zero_acc<4>(sa);
+        gemm_hd<LDH, NCH>(tK, q + RH * h, sa, i, grp);           // S[key][q]
+        float pf[16];
+        unpack_at<4>(sa, pf, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
+        mx = grp_max(mx);
+        float ls = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
+        ls = grp_sum(ls);
+        const float inv = 1.0f / ls;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pf[k] *= inv;
+        if (grp == 0) rowc[64 * h + 16 * w + i] = mx + __builtin_amdgcn_logf(ls);
+        store_row<4>(pf, st_p + 64 * h, grp);
+        accum_hd<LDH, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);   // O, this head's columns
+      }
+    }
+    W2STAMP(3);
+    // y = x + att Wo^T
+    GEMM_D(3 * NQ, of, y)
+    {
+      float x[R];
+      load_row<NCT>(x, xrow, grp);        // x again (L2): not kept live across the attention
+#pragma unroll
+      for (int k = 0; k < R; ++k) y[k] += x[k];
+    }
+  }
+  float r[R];
+  {
+    float zn[R];
+    {
+      float gm[R], bt[R], xh[R + 1];
+      load_row<NCT>(gm, pb + PB_LN2G, grp);
+      load_row<NCT>(bt, pb + PB_LN2B, grp);
+      ln_row<NCT>(y, gm, bt, xh, zn);
+    }
+    W2STAMP(4);
+    // hidden chunk mt (D units): a = LN2(y) W1[mt]^T + b1, z += gelu(a) W2[:, mt]^T
+    f32x4 zacc[NCT];
+    zero_acc<NCT>(zacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float am[R];
+      GEMM_D(4 * NQ + 2 * NQ * mt, zn, am)
+      {
+        float b1[R];
+        load_row<NCT>(b1, pb + mt * D, grp);
+#pragma unroll
+        for (int k = 0; k < R; k += 2) {
+          f32x2 g2, gp2;
+          cora_gelu_both2((f32x2){am[k] + b1[k], am[k + 1] + b1[k + 1]}, g2, gp2);
+          am[k] = g2.x; am[k + 1] = g2.y;
+          b1[k] = gp2.x; b1[k + 1] = gp2.y;
+        }
+        store_row<NCT>(b1, st_a + mt * D, grp);     // gelu'(a) waits in the stash for the backward
+      }
+      if (mt == 3) {      // x again and the next vode's rows: their latency runs under the last four tiles
+        load_row<NCT>(r, xrow, grp);
+        load_row<NCT>(zn, hnext, grp);
+      }
+      GEMM_D_ACC(5 * NQ + 2 * NQ * mt, am, zacc)
+    }
+    W2STAMP(5);
+    float z[R], b2[R];
+    unpack_at<NCT>(zacc, z, 0);
+    load_row<NCT>(b2, pb + PB_B2, grp);
+#pragma unroll
+    for (int k = 0; k < R; ++k) r[k] = zn[k] - (r[k] + y[k] + z[k] + b2[k]);          // e_{g+2} = h_next - u  (r held x, zn held h_next)
+    store_row<NCT>(r, p.E2 + (long long)g * nl + rowoff, grp);
+  }
+  W2STAMP(6);
+
+  // ---- backward (cotangent r) -----------------------------------------------------------------------
+  float dy[R];
+  {
+    // hidden chunk mt: da = (r W2)[mt] * gelu'(a), dzn += da W1[mt]
+    f32x4 dacc[NCT];
+    zero_acc<NCT>(dacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float dg[R], gp[R];
+      load_row<NCT>(gp, st_a + mt * D, grp);       // gelu'(a) of this chunk, back from the stash under the four tiles
+      GEMM_D(12 * NQ + 2 * NQ * mt, r, dg)
+#pragma unroll
+      for (int k = 0; k < R; ++k) dg[k] *= gp[k];
+      GEMM_D_ACC(13 * NQ + 2 * NQ * mt, dg, dacc)
+    }
+    W2STAMP(7);
+    // dy = r + LN2^T(dzn); LN2's normalised input is recomputed from y (still in registers)
+    float dzn[R], gm[R], xh[R + 1], tmp[R];
+    unpack_at<NCT>(dacc, dzn, 0);
+    load_row<NCT>(gm, pb + PB_LN2G, grp);
+    ln_row<NCT>(y, gm, nullptr, xh, tmp);
+    ln_bwd_row<NCT>(dzn, gm, xh, dy);
+#pragma unroll
+    for (int k = 0; k < R; ++k) dy[k] += r[k];
+  }
+  W2STAMP(8);
+  {
+    // dO = dy Wo; from here on r + dy is all that is needed of either
+    float dof[R];
+    GEMM_D(20 * NQ, dy, dof)
+#pragma unroll
+    for (int k = 0; k < R; ++k) r[k] += dy[k];
+    W2STAMP(9);
+    // attention backward, head by head on the four head tiles (K_h, V_h, Q_h, dO_h); dq lands in dy,
+    // dk / dv go to the stash until the last GEMM reads them
+    float* delta = rowc + 64 * H;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float ks[RH], vs[RH], pf[16], dp[16];
+      {
+        float qs[RH];
+        load_slice<NCH>(ks, st_k + 16 * NCH * h, grp);
+        load_slice<NCH>(vs, st_v + 16 * NCH * h, grp);
+        load_slice<NCH>(qs, st_q + 16 * NCH * h, grp);
+        load_row<4>(pf, st_p + 64 * h, grp);
+        __syncthreads();                 // the previous head's tiles are no longer read
+        put_slice<LDH, NCH>(ks, tA, w, i, grp);
+        put_slice<LDH, NCH>(vs, tB, w, i, grp);
+        put_slice<LDH, NCH>(qs, tC, w, i, grp);
+        put_slice<LDH, NCH>(dof + RH * h, tD, w, i, grp);
+      }
+      __syncthreads();
+      {
+        // pass A (own queries): dP[key][q] = V[key] . dO[q], delta = sum_key P dP, dS, dq
+        f32x4 sa[4];
+        zero_acc<4>(sa);
+        gemm_hd<LDH, NCH>(tB, dof + RH * h, sa, i, grp);
+        unpack_at<4>(sa, dp, 0);
+        float dl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+        dl = grp_sum(dl);
+        if (grp == 0) delta[64 * h + 16 * w + i] = dl;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);    // dS
+        accum_hd<LDH, NCH>(tA, dp, dy + RH * h, qscale, i, grp);      // dq (into dy)
+      }
+      __syncthreads();                   // delta of all 64 queries visible
+      {
+        // pass B (own keys): S and dP recomputed with the key on the lane; dV = P^T dO, dK = dS^T Q
+        float sp[16];
+        f32x4 sa[4];
+        zero_acc<4>(sa); gemm_hd<LDH, NCH>(tC, ks, sa, i, grp); unpack_at<4>(sa, sp, 0);     // S[q][key]
+        zero_acc<4>(sa); gemm_hd<LDH, NCH>(tD, vs, sa, i, grp); unpack_at<4>(sa, dp, 0);     // dP[q][key]
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const float4 l4 = *reinterpret_cast<const float4*>(&rowc[64 * h + 16 * tt + 4 * grp]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&delta[64 * h + 16 * tt + 4 * grp]);
+          float pv;
+          pv = __builtin_amdgcn_exp2f(sp[4 * tt + 0] * sc - l4.x); sp[4 * tt + 0] = pv; dp[4 * tt + 0] = pv * (dp[4 * tt + 0] - d4.x);
+          pv = __builtin_amdgcn_exp2f(sp[4 * tt + 1] * sc - l4.y); sp[4 * tt + 1] = pv; dp[4 * tt + 1] = pv * (dp[4 * tt + 1] - d4.y);
+          pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
+          pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
+        }
+        accum_hd<LDH, NCH>(tD, sp, vs, 1.0f, i, grp);       // dV (this head's columns)
+        accum_hd<LDH, NCH>(tC, dp, ks, qscale, i, grp);     // dK
+        store_slice<NCH>(ks, st_dkv + 16 * NCH * h, grp);
+        store_slice<NCH>(vs, st_dkv + D + 16 * NCH * h, grp);
+      }
+    }
+  }
+  W2STAMP(11);
+  {
+    // dxn = [dq | dk | dv] Wqkv: three K-chunks of Wqkv^T [D][3D]; dx = r + dy + LN1^T(dxn)
+    f32x4 xacc[NCT];
+    zero_acc<NCT>(xacc);
+    GEMM_D_ACC(21 * NQ, dy, xacc)
+    load_row<NCT>(dy, st_dkv, grp);             // dk (this wave wrote it itself: same lanes, no barrier needed)
+    GEMM_D_ACC(22 * NQ, dy, xacc)
+    load_row<NCT>(dy, st_dkv + D, grp);         // dv
+    GEMM_D_ACC(23 * NQ, dy, xacc)
+    W2STAMP(12);
+    float dxn[R], gm[R], xh[R + 1], tmp[R], x[R];
+    load_row<NCT>(x, xrow, grp);                 // LN1's normalised input is recomputed from x
+    unpack_at<NCT>(xacc, dxn, 0);
+    load_row<NCT>(gm, pb + PB_LN1G, grp);
+    ln_row<NCT>(x, gm, nullptr, xh, tmp);
+    ln_bwd_row<NCT>(dxn, gm, xh, dy);
+#pragma unroll
+    for (int k = 0; k < R; ++k) dy[k] += r[k];   // r holds r + dy
+    store_row<NCT>(dy, p.BP1 + (long long)g * nl + rowoff, grp);
+    W2STAMP(13);
+  }
+#undef STAGE
+#undef GEMM_CT
+#undef GEMM_D
+#undef GEMM_D_ACC
+#undef PREFETCH_ALL
+#undef WRITE_ALL
+#undef PF_ONE
+#undef PB_ONE
+}
+
+template <int NCT, int H>
+__global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // XCD-aware order (see fused_block.hip): XCD x gets a contiguous eighth of the (block, image) list
+  int j = (int)blockIdx.x;
+  const int n = p.L * p.B;
+  if ((n & 7) == 0) j = (j & 7) * (n >> 3) + (j >> 3);
+  wide2_block_body<NCT, H>(p, lds, j / p.B, j % p.B);
+}
+
+size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
+bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && H == 4 && M == 4 * D && P % 4 == 0; }
+
+int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
+  static bool attr[64] = {};
+  constexpr int NCT = 8, H = 4, D = 128, M = 512;
+  const size_t sm = (size_t)(2 * 32 * (D + 4) + 4 * 64 * 36 + 2 * H * 64 + M + 4 * D) * sizeof(float);
+  if (first_use_on_device(attr)) {
+    if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H>), dim3(L * p.B), dim3(256), sm, st, p);
+  return 0;
+}

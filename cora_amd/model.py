@@ -373,6 +373,10 @@ class TransformerDecoder:
             self._optim_sig = sig
         return rh
 
+    def kernel_path(self) -> str:
+        """"fused" (one workgroup per (block, image)) or "per-op" -- which kernels the step runs."""
+        return {1: "fused", 2: "fused-wide"}.get(_lib.load().cora_kernel_path(self._ctx), "per-op")
+
     # -- adam state (optimizer state is not part of the reference's checkpoints, but is exposed) ----
     def _reset_adam_state(self):
         """optim_w.init(model): AdamW moments and count back to zero (no-op before the ctx exists: a

@@ -10,9 +10,12 @@ fp32), and returns one row per compared tensor:
     {"err": max|gpu - fp64| / scale, "floor": max|fp32 oracle - fp64| / scale, "bar": the bar applied}
 
 scale = max|fp64| of that tensor (weight gradients: the largest entry over ALL weight gradients).
-bar = 1e-4 (BASELINE.json north_star) unless 3 x floor is larger -- then the fp32 restatement of the
-reference itself cannot meet 1e-4 on that tensor, the row says so ("bar" > 1e-4) and the GPU is held to
-3 x floor instead.
+bar = the PLAIN 1e-4 (BASELINE.json north_star) for everything north_star names -- final vodes, per-step
+energies, weight gradients -- and for final_w_energy / train_mse.  Only final_h_grad (gh*, the last
+step's dE/dh that train_on_batch returns for logging) is held to max(1e-4, 3 x floor): from
+forward-initialised vodes its upper layers are pure cancellation noise in ANY fp32 implementation (the
+fp32 oracle is up to 12x max|fp64| away from the fp64 oracle on gh1 of the 12-block case), the row says so
+("bar" > 1e-4).
 """
 from __future__ import annotations
 
@@ -85,6 +88,7 @@ def run_full_case(name: str):
     r32 = R.train_on_batch(*args, dtype=torch.float32)
     t2 = time.perf_counter()
     model = c["model"]
+    kernel_path = model.kernel_path()
     Eh, Ew, gh, gw, mse = ca.train_on_batch(T, c["x"], model=model, optim_w=c["optim_w"], optim_h=c["optim_h"])
     tot, per = ca.step_energies(model, T)
     rows = {}
@@ -94,7 +98,7 @@ def run_full_case(name: str):
         sc = (np.abs(want).max() + 1e-30) if scale is None else scale
         err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / sc)
         floor = float(np.abs(np.asarray(f32, dtype=np.float64) - want).max() / sc)
-        rows[key] = {"err": err, "floor": floor, "bar": max(TOL, 3.0 * floor)}
+        rows[key] = {"err": err, "floor": floor, "bar": max(TOL, 3.0 * floor) if key.startswith("gh") else TOL}
 
     put("energies[T]", tot, ref["energies"], r32["energies"])
     put("layer_energies[T,L+3]", per, ref["layer_energies"], r32["layer_energies"])
@@ -110,7 +114,7 @@ def run_full_case(name: str):
     info = {"config": FULL_CASES[name][0], "overrides": FULL_CASES[name][1], "B": c["B"], "T": T,
             "N": c["dims"].N, "D": c["dims"].D, "H": c["dims"].H, "L": L,
             "oracle_fp64_s": round(t1 - t0, 2), "oracle_fp32_s": round(t2 - t1, 2),
-            "kernel_path": "fused" if (c["dims"].N == 64 and c["dims"].P == 48 and c["dims"].D in (64, 96, 128)) else "per-op",
+            "kernel_path": kernel_path,
             "energy_first_last": [float(ref["energies"][0]), float(ref["energies"][-1])]}
     model.close()
     return rows, info

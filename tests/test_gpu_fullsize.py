@@ -17,9 +17,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B, clip_h, seed=5):
+def _setup(B, clip_h, seed=5, config="6block", **over):
+    import dataclasses
     import cora_amd as ca
-    mc = ca.MODEL_CONFIGS["6block"]
+    mc = ca.MODEL_CONFIGS[config]
+    if over:
+        mc = dataclasses.replace(mc, **over)
     tc = ca.transformer_config_from(mc)
     tc.use_status_init_in_training = False
     tc.update_weights_every_inference_step = False
@@ -60,9 +63,15 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def test_fused_and_per_op_paths_agree_at_full_size():
-    ca, mc, tc, x, h0 = _setup(200, mc_clip := 2000.0)
-    T = 20
+@pytest.mark.parametrize("config,over,T", [
+    ("6block", {}, 20),                                     # cfg 2: the D = 64 fused kernel
+    ("12block", {}, 20),                                    # cfg 3 canonical: D = 128, H = 4 on the wide fused kernel
+    ("12block", {"hidden_size": 128, "num_heads": 1}, 6),   # head dim 128: P / dS handed over through LDS
+    ("12block", {"hidden_size": 96, "num_heads": 4}, 6),    # head dim 24: heads share a column group
+    ("12block", {"hidden_size": 96, "num_heads": 2}, 6),
+])
+def test_fused_and_per_op_paths_agree_at_full_size(config, over, T):
+    ca, mc, tc, x, h0 = _setup(200, mc_clip := 2000.0, config=config, **over)
     a = _run(ca, mc, tc, x, h0, T, mc_clip, fused=True)
     b = _run(ca, mc, tc, x, h0, T, mc_clip, fused=False)
     assert np.isfinite(a["tot"]).all() and np.isfinite(b["tot"]).all()

@@ -1,9 +1,10 @@
 """HIP path against the fp64 oracle at the sizes bench.py measures and at T = 20 chained inference
 steps: config 2 (6block) at B = 200, config 1's recipe (scheduled eta_h, base 1.1, c_h 1000, mu 0.1),
 the canonical 12-block sweep point (D = 128, H = 4) and its D = 96 sibling, the 1024-token video shape
-and the ImageNet 224/16 shape with all 6 blocks.  Bar per tensor: 1e-4, or 3 x the fp32 oracle's own
-distance from the fp64 oracle where that is larger (tests/parity_cases.py); `scripts/parity_table.py`
-writes every tensor's (err, floor, bar) to profiles/r2_parity_table.json."""
+and the ImageNet 224/16 shape with all 6 blocks.  Bar: the plain 1e-4 on final vodes, per-step energies,
+weight gradients, final_w_energy and train_mse; max(1e-4, 3 x fp32-oracle floor) on final_h_grad only
+(tests/parity_cases.py says why); `scripts/parity_table.py` writes every tensor's (err, floor, bar) to
+profiles/r2_parity_table.json."""
 import json
 import os
 
@@ -25,8 +26,4 @@ def test_full_size_oracle_parity(name):
             json.dump({"info": info, "rows": rows}, f, indent=1)
     bad = {k: v for k, v in rows.items() if not v["err"] <= v["bar"]}
     assert not bad, f"{name}: parity failures {bad}"
-    # what north_star names (final vodes, per-step energies, weight gradients) must not lean on the floor
-    # by more than the fp32 restatement itself does: report, and fail if the GPU is worse than 1e-4 while the
-    # fp32 oracle is comfortably inside it
-    lean = {k: v for k, v in rows.items() if v["err"] > TOL and v["floor"] < TOL / 3}
-    assert not lean, f"{name}: above 1e-4 although the fp32 oracle is not: {lean}"
+    assert all(v["bar"] == TOL for k, v in rows.items() if not k.startswith("gh"))

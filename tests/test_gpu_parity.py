@@ -3,12 +3,15 @@
 Tolerance (BASELINE.json north_star): fp32 path, rel <= 1e-4 on final vodes, per-step energies and
 weight gradients.  `relerr` is max|a-b| / max|b| per tensor.
 
-fp32 noise floor.  The double residual u_{l+1} = 2 h_l + ... makes forward-initialised vodes grow
-like 2^l, so e_l = h_l - u_l cancels ~l bits in ANY fp32 implementation (the reference's JAX path
-included): at 12 blocks the fp32 CPU restatement itself is 1e-3 away from the fp64 one on dE/dh of
-the deepest vodes.  Each quantity is therefore held to  max(1e-4, 3 x floor)  where `floor` is
-the error of the oracle run in fp32 against the oracle run in fp64 on the same inputs; wherever
-the floor is below 3e-5 (all shallow cases, all energies and vodes) this is the plain 1e-4 bar.
+Bars.  What north_star names -- final vodes, per-step energies (total and per vode), the weight
+gradients, plus the two scalars of the 5-tuple (final_w_energy, train_mse) -- is held to the PLAIN
+1e-4, no relaxation (measured: <= 3e-6 on every case incl. B=200 / T=20 / 12 blocks,
+profiles/r2_parity_table.json).  Only `final_h_grad` (gh*: the last step's dE/dh, returned by
+train_on_batch for logging) gets a noise-floor rule: the double residual u_{l+1} = 2 h_l + ... makes
+forward-initialised vodes grow like 2^l, so e_l = h_l - u_l cancels ~l bits in ANY fp32
+implementation (the reference's JAX path included) and at 12 blocks the fp32 CPU restatement itself
+is 1e-3 .. 10x away from the fp64 one on dE/dh of the upper vodes.  gh* is held to
+max(1e-4, 3 x floor), floor = error of the oracle run in fp32 against the oracle run in fp64.
 
 AdamW's first steps divide by |g|+eps, which amplifies fp32 noise in near-zero gradient entries
 without bound, so the updated weights are checked against the oracle's AdamW applied to the
@@ -86,10 +89,18 @@ def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=Fal
         errs["adamw" + k] = relerr(neww[k], want)
         floor["adamw" + k] = 0.0
     model.close()
-    bad = {k: (v, floor[k]) for k, v in errs.items()
-           if not (v <= (1e-5 if k.startswith("adamw") else max(TOL, 3.0 * floor[k])))}
+    bad = {k: (v, floor[k]) for k, v in errs.items() if not v <= bar_for(k, floor[k])}
     assert not bad, f"{name}: parity failures (err, fp32 floor): {bad}"
     return (errs, floor) if return_floor else errs
+
+
+def bar_for(key, floor):
+    """1e-5 for the AdamW kernel check, max(1e-4, 3 x fp32 floor) for final_h_grad, plain 1e-4 for the rest."""
+    if key.startswith("adamw"):
+        return 1e-5
+    if key.startswith("gh"):
+        return max(TOL, 3.0 * floor)
+    return TOL
 
 
 @pytest.mark.parametrize("name", list(CASES))

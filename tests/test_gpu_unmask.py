@@ -29,7 +29,9 @@ def _cmp(errs, floor, key, got, want, f32):
 
 
 def _check(name, errs, floor):
-    bad = {k: (v, floor[k]) for k, v in errs.items() if not v <= max(TOL, 3.0 * floor[k])}
+    # plain 1e-4, except the per-step gradient NORMS (a logging quantity: dE/dh is cancellation noise on the
+    # upper vodes in any fp32 implementation, see tests/test_gpu_parity.py), held to max(1e-4, 3 x fp32 floor)
+    bad = {k: (v, floor[k]) for k, v in errs.items() if not v <= (max(TOL, 3.0 * floor[k]) if "gnorm" in k else TOL)}
     assert not bad, f"{name}: parity failures (err, fp32 floor): {bad}"
 
 
