@@ -502,25 +502,15 @@ int infer_grad_step(cora_ctx* c, int t) {
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
     launch_vode_grad(v, c->st);
   } else if (c->fusedw) {
-    // wide fused kernel (D = 96 / 128): the two edge layers as four small GEMMs, then one launch for all L
-    // blocks (e_2..e_{L+1} and J^T e for vodes 1..L), then vode_grad as on the D = 64 path
+    // wide fused kernel (D = 96 / 128): one launch for all L blocks (e_2..e_{L+1} and J^T e for vodes 1..L) and,
+    // in B extra workgroups, the two edge layers (e_1, g_0, e_img, J^T e for vode L+1); then vode_grad as on
+    // the D = 64 path
     double* es = c->esum + (long long)t * (L + 3) * 8;
-    patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), nullptr);   // e_1 (its energy comes from vode_grad)
-    out_proj(c, vode_ptr(c, c->Hs, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, es + (long long)(L + 2) * 8);   // e_img + sensory energy
-    GemmP p = gemm_base(c, 1);       // g_0 = -s_0 e_1 Wp
-    p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
-    p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
-    p.mode = OUT_GRAD; p.alpha2 = c->scale_l[0]; p.red = ss + 0;
-    run_gemm(c, p, false, true);
-    p = gemm_base(c, 1);             // J^T e for vode L+1 = e_img Wout
-    p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
-    p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
-    p.mode = OUT_STORE;
-    run_gemm(c, p, false, true);
     FusedP f;
     fill_fused(c, f, nullptr, ss);
+    f.esens = es + (long long)(L + 2) * 8;
     {
-      KScope s(c, K_FUSED, block_step_flops(c), 4.0 * 4 * L * c->nl);
+      KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl);
       if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);

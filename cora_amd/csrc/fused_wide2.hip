@@ -492,6 +492,10 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
 template <int NCT, int H>
 __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
+    edge_path_wide<NCT>(p, lds, (int)blockIdx.x - p.L * p.B);
+    return;
+  }
   // XCD-aware order (see fused_block.hip): XCD x gets a contiguous eighth of the (block, image) list
   int j = (int)blockIdx.x;
   const int n = p.L * p.B;
@@ -509,6 +513,6 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
   }
-  hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H>), dim3(L * p.B), dim3(256), sm, st, p);
+  hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }

@@ -280,4 +280,88 @@ __device__ __forceinline__ void head_backward_b(const float* bufQ, const float* 
   __builtin_amdgcn_sched_barrier(0);
 }
 
+
+// ---- edge layers of one image (one extra workgroup per image in the wide kernels' grids) ------------
+//   e_1 = h_1 - (h_0 Wp^T + bp + pos)          g_0 = -s_0 e_1 Wp              (vode 0 has no own energy)
+//   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by vode_grad_kernel)
+// (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153).  P = 48 (patch 4 x 4 x 3).
+// The two halves run one after the other through the same LDS (Wp + Wp^T, then Wout + Wout^T: 52 KB).
+__device__ __forceinline__ void edge_copy_to_lds(float* dst, const float* src, int rows, int cols, int ldt, int tid) {
+  const int c4n = cols / 4;
+  for (int f = tid; f < rows * c4n; f += 256) {
+    const int rr = f / c4n, c4 = f % c4n;
+    *reinterpret_cast<float4*>(&dst[rr * ldt + 4 * c4]) = *reinterpret_cast<const float4*>(src + (long long)rr * cols + 4 * c4);
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void edge_path_wide(const FusedP& p, float* lds, int b) {
+  constexpr int D = 16 * NCT, P = 48, LP = P + 4, LDD = D + 4, R = 4 * NCT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  float* sA = lds;                   // [D][LP]    Wp   [D][P]   /  Wout^T [D][P]
+  float* sB = lds + D * LP;          // [P][LDD]   Wp^T [P][D]   /  Wout   [P][D]
+  const long long tok = (long long)b * 64 + 16 * w + i;     // token row of this lane
+  const long long nl = (long long)p.B * 64 * D;
+  edge_copy_to_lds(sA, p.W + p.oWp, D, P, LP, tid);
+  edge_copy_to_lds(sB, p.WT + p.tWp, P, D, LDD, tid);
+  float e1[R];
+  {
+    float h0[12];
+    load_row<3>(h0, p.H0 + tok * P, grp);
+    load_row<NCT>(e1, p.H1 + tok * D, grp);                  // h_1
+    __syncthreads();
+    f32x4 acc[NCT];
+    zero_acc<NCT>(acc);
+    gemm_tile_w<NCT, 3, LP>(sA, h0, acc, i, grp);
+    float u[R], bp[R], ps[R];
+    unpack_at<NCT>(acc, u, 0);
+    load_row<NCT>(bp, p.W + p.obp, grp);
+    load_row<NCT>(ps, p.pos + (long long)(16 * w + i) * D, grp);
+#pragma unroll
+    for (int k = 0; k < R; ++k) e1[k] = e1[k] - (u[k] + bp[k] + ps[k]);
+    store_row<NCT>(e1, p.E1 + tok * D, grp);
+  }
+  {
+    f32x4 acc[3];
+    zero_acc<3>(acc);
+    gemm_tile_w<3, NCT, LDD>(sB, e1, acc, i, grp);
+    float g0[12];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float v = -p.s0 * acc[k][j]; g0[4 * k + j] = v; ss += (double)v * v; }
+    store_row<3>(g0, p.G0 + tok * P, grp);
+    ss = wave_sum_d(ss);
+    if (lane == 0) atomicAdd(&p.sumsq0[(b * 4 + w) & 7], ss);
+  }
+  __syncthreads();                   // both tiles are no longer read
+  edge_copy_to_lds(sB, p.W + p.oWout, P, D, LDD, tid);
+  edge_copy_to_lds(sA, p.WT + p.tWout, D, P, LP, tid);
+  {
+    float hl[R], xp[12], bo[12], ei[12];
+    load_row<NCT>(hl, p.H1 + (long long)p.L * nl + tok * D, grp);
+    load_row<3>(xp, p.XP + tok * P, grp);
+    load_row<3>(bo, p.W + p.obout, grp);
+    __syncthreads();
+    f32x4 acc[3];
+    zero_acc<3>(acc);
+    gemm_tile_w<3, NCT, LDD>(sB, hl, acc, i, grp);
+    float en = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float e = xp[4 * k + j] - (acc[k][j] + bo[4 * k + j]); ei[4 * k + j] = e; en += 0.5f * e * e; }
+    store_row<3>(ei, p.EIMG + tok * P, grp);
+    const double tot = wave_sum_d((double)en);
+    if (lane == 0) atomicAdd(&p.esens[(b * 4 + w) & 7], tot);          // vode L+2 (sensory): plain se_energy
+    f32x4 acc2[NCT];
+    zero_acc<NCT>(acc2);
+    gemm_tile_w<NCT, 3, LP>(sA, ei, acc2, i, grp);
+    float bpl[R];
+    unpack_at<NCT>(acc2, bpl, 0);
+    store_row<NCT>(bpl, p.BP1 + (long long)p.L * nl + tok * D, grp);
+  }
+}
+
 }  // namespace
