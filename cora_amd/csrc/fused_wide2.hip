@@ -71,6 +71,42 @@ __device__ __forceinline__ void put_slice(const float* xs, float* tile, int w, i
 #pragma unroll
   for (int c = 0; c < NCH; ++c) lds_st4(d + 16 * c, make_float4(xs[4 * c], xs[4 * c + 1], xs[4 * c + 2], xs[4 * c + 3]));
 }
+// Transposed head tile T^T[col][token] (row stride LDT): the "sum over tokens" products read their A
+// operand as one ds_read_b128 per 4 MFMAs instead of one ds_read_b32 per MFMA.
+template <int LDT, int NCH>
+__device__ __forceinline__ void put_slice_t(const float* xs, float* tile, int w, int i, int grp) {
+  lds_float* d = opaque_w(tile + 4 * grp * LDT + 16 * w + i);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) d[(16 * c + reg) * LDT] = xs[4 * c + reg];
+}
+// out[4 c + reg'] = scale * sum over the 64 tokens j of T^T[16 c + 4 grp + reg'][j] * pf[j]
+template <int LDT, int NCH>
+__device__ __forceinline__ void accum_t(const float* __restrict__ tt_, const float* pf, float* out, float scale, int i, int grp) {
+  f32x4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const lds_float* tl = opaque(tt_ + i * LDT + 4 * grp);
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    float4 a[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a[c] = lds_ld4(&tl[16 * c * LDT + 16 * tt]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = mfma16(a[c].x, pf[4 * tt + 0], acc[c]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = mfma16(a[c].y, pf[4 * tt + 1], acc[c]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = mfma16(a[c].z, pf[4 * tt + 2], acc[c]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = mfma16(a[c].w, pf[4 * tt + 3], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[4 * c + reg] = acc[c][reg] * scale;
+}
 template <int NCH>
 __device__ __forceinline__ void load_slice(float* f, const float* base, int grp) {   // base = row pointer + 16 * first column group
 #pragma unroll
@@ -112,6 +148,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   constexpr int NST = TR * D / 4 / 256;           // staged float4 per thread and tile (4)
   constexpr int DH = D / H, NCH = DH / 16, RH = 4 * NCH;   // head dim 32: 2 column groups, 8 registers per slice
   constexpr int LDH = DH + 4, HT = 64 * LDH;      // head tile [64][36]
+  constexpr int LDT = 64 + 4;                     // transposed head tile [32][68] (fits the same slot)
+  static_assert(DH * LDT <= HT, "transposed tile fits a head-tile slot");
   constexpr int NT = 24 * NQ;                     // 96 tiles
   static_assert(DH == 32 && TR * D % 1024 == 0 && NST * 2 <= NCT, "built for heads of 32");
   const float qscale = rsqrtf((float)DH);
@@ -281,9 +319,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     for (int hp = 0; hp < H; hp += 2) {
       __syncthreads();                   // the previous round's tiles are no longer read
       put_slice<LDH, NCH>(kk + RH * hp, tA, w, i, grp);
-      put_slice<LDH, NCH>(v + RH * hp, tB, w, i, grp);
+      put_slice_t<LDT, NCH>(v + RH * hp, tB, w, i, grp);
       put_slice<LDH, NCH>(kk + RH * (hp + 1), tC, w, i, grp);
-      put_slice<LDH, NCH>(v + RH * (hp + 1), tD, w, i, grp);
+      put_slice_t<LDT, NCH>(v + RH * (hp + 1), tD, w, i, grp);
       __syncthreads();
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -308,7 +346,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         for (int k = 0; k < 16; ++k) pf[k] *= inv;
         if (grp == 0) rowc[64 * h + 16 * w + i] = mx + __builtin_amdgcn_logf(ls);
         store_row<4>(pf, st_p + 64 * h, grp);
-        accum_hd<LDH, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);   // O, this head's columns
+        accum_t<LDT, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);    // O, this head's columns (V_h transposed)
       }
     }
     W2STAMP(3);
