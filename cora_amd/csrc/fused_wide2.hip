@@ -437,8 +437,18 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
 #pragma unroll
     for (int k = 0; k < R; ++k) r[k] += dy[k];
     W2STAMP(9);
-    // attention backward, head by head on the four head tiles (K_h, V_h, Q_h, dO_h); dq lands in dy,
-    // dk / dv go to the stash until the last GEMM reads them
+    // attention backward, head by head.  Six head tiles: V_h, Q_h, dO_h row-major (the score-shaped products
+    // contract over the head dim) and K_h, Q_h, dO_h transposed (dq, dK, dV sum over tokens: one 128-bit
+    // LDS read per four MFMAs).  They fill the four forward tile slots plus the weight slot that is free
+    // here (tile 21 NQ already sits in slot 0, tile 21 NQ + 1 in registers).  dq lands in dy, dk / dv go
+    // to the stash until the last GEMM reads them.
+    static_assert((21 * NQ) % 2 == 0 && 3 * HT + 3 * DH * LDT <= SLOT + 4 * HT, "six backward head tiles fit slot 1 + the head tiles");
+    float* bV = wbuf + SLOT;
+    float* bKT = bV + HT;
+    float* bQ = bKT + DH * LDT;
+    float* bdO = bQ + HT;
+    float* bQT = bdO + HT;
+    float* bdOT = bQT + DH * LDT;
     float* delta = rowc + 64 * H;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -449,18 +459,20 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         load_slice<NCH>(vs, st_v + 16 * NCH * h, grp);
         load_slice<NCH>(qs, st_q + 16 * NCH * h, grp);
         load_row<4>(pf, st_p + 64 * h, grp);
-        __syncthreads();                 // the previous head's tiles are no longer read
-        put_slice<LDH, NCH>(ks, tA, w, i, grp);
-        put_slice<LDH, NCH>(vs, tB, w, i, grp);
-        put_slice<LDH, NCH>(qs, tC, w, i, grp);
-        put_slice<LDH, NCH>(dof + RH * h, tD, w, i, grp);
+        __syncthreads();                 // the previous head's tiles (and weight tile 21 NQ - 1) are no longer read
+        put_slice<LDH, NCH>(vs, bV, w, i, grp);
+        put_slice_t<LDT, NCH>(ks, bKT, w, i, grp);
+        put_slice<LDH, NCH>(qs, bQ, w, i, grp);
+        put_slice<LDH, NCH>(dof + RH * h, bdO, w, i, grp);
+        put_slice_t<LDT, NCH>(qs, bQT, w, i, grp);
+        put_slice_t<LDT, NCH>(dof + RH * h, bdOT, w, i, grp);
       }
       __syncthreads();
       {
         // pass A (own queries): dP[key][q] = V[key] . dO[q], delta = sum_key P dP, dS, dq
         f32x4 sa[4];
         zero_acc<4>(sa);
-        gemm_hd<LDH, NCH>(tB, dof + RH * h, sa, i, grp);
+        gemm_hd<LDH, NCH>(bV, dof + RH * h, sa, i, grp);
         unpack_at<4>(sa, dp, 0);
         float dl = 0.f;
 #pragma unroll
@@ -469,15 +481,15 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         if (grp == 0) delta[64 * h + 16 * w + i] = dl;
 #pragma unroll
         for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);    // dS
-        accum_hd<LDH, NCH>(tA, dp, dy + RH * h, qscale, i, grp);      // dq (into dy)
+        accum_t<LDT, NCH>(bKT, dp, dy + RH * h, qscale, i, grp);      // dq (into dy)
       }
       __syncthreads();                   // delta of all 64 queries visible
       {
         // pass B (own keys): S and dP recomputed with the key on the lane; dV = P^T dO, dK = dS^T Q
         float sp[16];
         f32x4 sa[4];
-        zero_acc<4>(sa); gemm_hd<LDH, NCH>(tC, ks, sa, i, grp); unpack_at<4>(sa, sp, 0);     // S[q][key]
-        zero_acc<4>(sa); gemm_hd<LDH, NCH>(tD, vs, sa, i, grp); unpack_at<4>(sa, dp, 0);     // dP[q][key]
+        zero_acc<4>(sa); gemm_hd<LDH, NCH>(bQ, ks, sa, i, grp); unpack_at<4>(sa, sp, 0);      // S[q][key]
+        zero_acc<4>(sa); gemm_hd<LDH, NCH>(bdO, vs, sa, i, grp); unpack_at<4>(sa, dp, 0);     // dP[q][key]
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const float4 l4 = *reinterpret_cast<const float4*>(&rowc[64 * h + 16 * tt + 4 * grp]);
@@ -488,8 +500,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
           pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
           pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
         }
-        accum_hd<LDH, NCH>(tD, sp, vs, 1.0f, i, grp);       // dV (this head's columns)
-        accum_hd<LDH, NCH>(tC, dp, ks, qscale, i, grp);     // dK
+        accum_t<LDT, NCH>(bdOT, sp, vs, 1.0f, i, grp);       // dV (this head's columns)
+        accum_t<LDT, NCH>(bQT, dp, ks, qscale, i, grp);      // dK
         store_slice<NCH>(ks, st_dkv + 16 * NCH * h, grp);
         store_slice<NCH>(vs, st_dkv + D + 16 * NCH * h, grp);
       }
