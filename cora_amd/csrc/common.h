@@ -121,6 +121,9 @@ struct GemmP {
 };
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
+// bf16 mode, both operands K-inner (gemm_bf16.hip): operands rounded to bf16 while staging into LDS
+bool gemm_bf16_nt_supported(const GemmP& p);
+void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st);
 #define GEMM_MULTI_MAX 6
 struct GemmMulti { int n; int start[GEMM_MULTI_MAX + 1]; GemmP p[GEMM_MULTI_MAX]; };
 // n independent K-outer x K-outer (TN) problems in one launch; start[] is filled by the launcher

@@ -267,6 +267,15 @@ void run_gemm(cora_ctx* c, const GemmP& p, bool ako, bool bko) {
   launch_gemm(p, ako, bko, c->st);
 }
 
+// Weight operand of a backward-data GEMM (contraction over the weight's OUTPUT index): K-outer as stored.
+// In bf16 mode the GEMMs read the transposed copy instead -- K-inner, the one operand form the
+// bf16-staged kernel (gemm_bf16.hip) takes.  Sets p.Bw / p.ldb (p.K and p.O already set); returns b_kouter.
+bool bwd_weight(cora_ctx* c, GemmP& p, size_t w_off, size_t wt_off) {
+  if (c->cfg.dtype_mode == 1 && c->WT) { p.Bw = c->WT + wt_off; p.ldb = p.K; return false; }
+  p.Bw = c->W + w_off; p.ldb = p.O;
+  return true;
+}
+
 // patch projection: u_1 = h_0 Wp^T + bp + pos   (src/decoder_transformer.py:222-228)
 void patch_proj(cora_ctx* c, const float* h0, float* out, int mode, const float* tgt, double* red) {
   GemmP p = gemm_base(c);
@@ -353,17 +362,17 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   const long long rows = (long long)G * R;
   GemmP p = gemm_base(c, 1); p.groups = G;
   // da = (r W2) * gelu'(a)
-  p.A = r; p.Bw = c->W + c->oW2 + (size_t)b0 * D * M; p.C = c->da;
-  p.R = R; p.O = M; p.K = D; p.lda = D; p.ldb = M; p.ldc = M;
+  p.A = r; p.C = c->da;
+  p.R = R; p.O = M; p.K = D; p.lda = D; p.ldc = M;
   p.sA = (long long)R * D; p.sB = (long long)D * M; p.sC = (long long)R * M;
   p.mode = OUT_GELUGRAD; p.aux = c->a;
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bwd_weight(c, p, c->oW2 + (size_t)b0 * D * M, c->tW2 + (size_t)b0 * D * M));
   // dzn = da W1
   p = gemm_base(c, 1); p.groups = G;
-  p.A = c->da; p.Bw = c->W + c->oW1 + (size_t)b0 * M * D; p.C = c->dzn;
-  p.R = R; p.O = D; p.K = M; p.lda = M; p.ldb = D; p.ldc = D;
+  p.A = c->da; p.C = c->dzn;
+  p.R = R; p.O = D; p.K = M; p.lda = M; p.ldc = D;
   p.sA = (long long)R * M; p.sB = (long long)M * D; p.sC = (long long)R * D;
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bwd_weight(c, p, c->oW1 + (size_t)b0 * M * D, c->tW1 + (size_t)b0 * M * D));
   {
     LnBwdP q; memset(&q, 0, sizeof q);
     q.dxn = c->dzn; q.x = c->y; q.stats = c->st2; q.gamma = c->W + c->oLn2g + (size_t)b0 * D; q.sParam = D;
@@ -373,10 +382,10 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   }
   // dO = dy Wo
   p = gemm_base(c, 1); p.groups = G;
-  p.A = c->dy; p.Bw = c->W + c->oWo + (size_t)b0 * D * D; p.C = c->dO;
-  p.R = R; p.O = D; p.K = D; p.lda = D; p.ldb = D; p.ldc = D;
+  p.A = c->dy; p.C = c->dO;
+  p.R = R; p.O = D; p.K = D; p.lda = D; p.ldc = D;
   p.sA = (long long)R * D; p.sB = (long long)D * D; p.sC = (long long)R * D;
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bwd_weight(c, p, c->oWo + (size_t)b0 * D * D, c->tWo + (size_t)b0 * D * D));
   {
     double fl = 14.0 * G * c->B * (double)c->N * c->N * D;   // 7 products (S and dP are recomputed per side)
     KScope s(c, K_ATTN_BWD, fl, 4.0 * rows * 9 * D);
@@ -384,10 +393,10 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   }
   // dxn = dqkv Wqkv
   p = gemm_base(c, 1); p.groups = G;
-  p.A = c->dqkv; p.Bw = c->W + c->oWqkv + (size_t)b0 * 3 * D * D; p.C = c->dxn;
-  p.R = R; p.O = D; p.K = 3 * D; p.lda = 3 * D; p.ldb = D; p.ldc = D;
+  p.A = c->dqkv; p.C = c->dxn;
+  p.R = R; p.O = D; p.K = 3 * D; p.lda = 3 * D; p.ldc = D;
   p.sA = (long long)R * 3 * D; p.sB = 3LL * D * D; p.sC = (long long)R * D;
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bwd_weight(c, p, c->oWqkv + (size_t)b0 * 3 * D * D, c->tWqkv + (size_t)b0 * 3 * D * D));
   if (gout) {
     LnBwdP q; memset(&q, 0, sizeof q);
     q.dxn = c->dxn; q.x = xin; q.stats = c->st1; q.gamma = c->W + c->oLn1g + (size_t)b0 * D; q.sParam = D;
@@ -401,7 +410,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
 
 // transposed weight copies (W^T) read by the fused kernel's backward GEMMs
 void refresh_wt(cora_ctx* c) {
-  if (!c->fused && !c->fusedw) return;
+  if (!c->WT) return;
   const int D = c->D, M = c->M, L = c->L;
   KScope s(c, K_OTHER, 0, 8.0 * c->nWT);
   TransposeSet t; memset(&t, 0, sizeof t);
@@ -526,21 +535,22 @@ int infer_grad_step(cora_ctx* c, int t) {
   if (!c->fused && !c->fusedw) {
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c, 1);
-  p.A = err_ptr(c, 1); p.Bw = c->W + c->oWp; p.C = vode_ptr(c, c->Gs, 0);
-  p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldb = c->P; p.ldc = c->P;
+  p.A = err_ptr(c, 1); p.C = vode_ptr(c, c->Gs, 0);
+  p.R = (int)c->BN; p.O = c->P; p.K = c->D; p.lda = c->D; p.ldc = c->P;
   p.mode = OUT_GRAD; p.alpha2 = c->scale_l[0]; p.red = ss + 0;
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bwd_weight(c, p, c->oWp, c->tWp));
   // vode L+1: g = e_{L+1} + reg - e_img Wout
   p = gemm_base(c, 1);
-  p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = vode_ptr(c, c->Gs, L + 1);
-  p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldb = c->D; p.ldc = c->D;
+  p.A = err_ptr(c, L + 2); p.C = vode_ptr(c, c->Gs, L + 1);
+  p.R = (int)c->BN; p.O = c->D; p.K = c->P; p.lda = c->P; p.ldc = c->D;
+  const bool bko_out = bwd_weight(c, p, c->oWout, c->tWout);
   if (c->vln) {   // cotangent w.r.t. the NORMALISED vode L+1; LN_L^T and the assembly follow below
     p.C = c->dxr + (long long)L * c->nl; p.mode = OUT_STORE;
   } else {
     p.mode = OUT_GRAD; p.alpha2 = c->scale_l[L + 1]; p.tgt = err_ptr(c, L + 1); p.hreg = vode_ptr(c, c->Hs, L + 1);
     p.l1 = c->cfg.l1; p.l2 = c->cfg.l2; p.red = ss + 8 * (L + 1);
   }
-  run_gemm(c, p, false, true);
+  run_gemm(c, p, false, bko_out);
   if (L > 0) {
     if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true);
     else rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
@@ -754,7 +764,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->fusedw = (!c->fused && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_wide_supported(c->N, c->P, c->D, c->H, c->M) &&
                getenv("CORA_NO_FUSED") == nullptr);
   c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
-  if (c->fused || c->fusedw) {
+  if (c->fused || c->fusedw || cfg->dtype_mode == 1) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
@@ -1145,9 +1155,9 @@ int enqueue_wgrad(cora_ctx* c) {
   }
   if (c->vln) {   // vode LayerNorm parameters: d gamma_v = -sum dx'_v * xhat_v, d beta_v = -sum dx'_v
     GemmP p = gemm_base(c, 1);
-    p.A = err_ptr(c, L + 2); p.Bw = c->W + c->oWout; p.C = c->dxr + (long long)L * c->nl;
-    p.R = R; p.O = D; p.K = P; p.lda = P; p.ldb = D; p.ldc = D; p.mode = OUT_STORE;
-    run_gemm(c, p, false, true);                                  // dx'_{L+1} = e_img Wout
+    p.A = err_ptr(c, L + 2); p.C = c->dxr + (long long)L * c->nl;
+    p.R = R; p.O = D; p.K = P; p.lda = P; p.ldc = D; p.mode = OUT_STORE;
+    run_gemm(c, p, false, bwd_weight(c, p, c->oWout, c->tWout));  // dx'_{L+1} = e_img Wout
     KScope s(c, K_OTHER, 0, 12.0 * (L + 1) * R * D);
     launch_colsum(c->dxr, vode_ptr(c, c->Hs, 1), c->stv, c->dW + c->oVg, D, R, L + 1, D, -1.f, c->st);
     launch_colsum(c->dxr, nullptr, nullptr, c->dW + c->oVb, D, R, L + 1, D, -1.f, c->st);

@@ -17,6 +17,7 @@
 // k is permuted inside each 8-deep group so K-inner operands are fetched with one ds_read_b128:
 // MFMA t of group j sees k = 8j + 4*(lane>>5) + t on both operands.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 #define BM 128
 #define BN 64
@@ -203,108 +204,12 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const in
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
-  const long long offC = (long long)g * p.sC;
-  float* C = p.C + offC;
-  const float* bias = p.bias ? p.bias + (long long)g * p.sBias : nullptr;
-  const float* res1 = p.res1 ? p.res1 + offC : nullptr;
-  const float* res2 = p.res2 ? p.res2 + offC : nullptr;
-  const float* tgt = p.tgt ? p.tgt + offC : nullptr;
-  const float* hreg = p.hreg ? p.hreg + offC : nullptr;
-  const float* aux = p.aux ? p.aux + offC : nullptr;
-#ifndef EPB
-#define EPB 16
-#endif
+  // ---- epilogue (gemm_epilogue.h) -------------------------------------------------------------
+  const GemmEp q = gemm_ep_ptrs(p, g);
   double red = 0.0;
-  // Every operand the epilogue reads is fetched for EPB values at a time BEFORE the first store of that
-  // batch: the compiler must assume C aliases them, and a load -> wait -> store chain per element costs
-  // one exposed HBM latency per element.  Offsets are 32-bit (the launcher checks R * ldc < 2^31) to keep
-  // the batch's address registers from pushing the kernel below 4 waves per SIMD.
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int col = col0 + 32 * n + r;
-    const bool colok = col < p.O;
-    const float bv = (bias && colok) ? bias[col] : 0.f;
-    const int rbase = row0 + 32 * w + 4 * hi;
-    const int obase = rbase * p.ldc + col;
-#pragma unroll
-    for (int half = 0; half < 16 / EPB; ++half) {
-#define EP_ROW(i) (rbase + ((i) & 3) + 8 * ((EPB / 4) * half + ((i) >> 2)))
-#define EP_OK(i) (colok && EP_ROW(i) < p.R)
-#define EP_IDX(i) (obase + (((i) & 3) + 8 * ((EPB / 4) * half + ((i) >> 2))) * p.ldc)
-#define EP_FETCH(dst, src)                                                                   \
-      _Pragma("unroll") for (int i = 0; i < EPB; ++i) dst[i] = EP_OK(i) ? (src)[EP_IDX(i)] : 0.f
-      float v[EPB], t0[EPB];
-#pragma unroll
-      for (int i = 0; i < EPB; ++i) v[i] = p.alpha * acc[n][EPB * half + i] + bv;
-      if (p.pos) {
-#pragma unroll
-        for (int i = 0; i < EPB; ++i) t0[i] = EP_OK(i) ? p.pos[(EP_ROW(i) % p.posN) * p.O + col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
-      }
-      if (res1) {
-        EP_FETCH(t0, res1);
-#pragma unroll
-        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
-      }
-      if (res2) {
-        EP_FETCH(t0, res2);
-#pragma unroll
-        for (int i = 0; i < EPB; ++i) v[i] += t0[i];
-      }
-      switch (p.mode) {
-        case OUT_STORE:
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) C[EP_IDX(i)] = v[i];
-          break;
-        case OUT_ERR: {
-          EP_FETCH(t0, tgt);
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) {
-            const float h = t0[i], e = h - v[i];
-            C[EP_IDX(i)] = e;
-            red += (double)(0.5f * e * e + p.l1 * fabsf(h) + p.l2 * h * h);
-          }
-        } break;
-        case OUT_GELUGRAD: {
-          EP_FETCH(t0, aux);
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) C[EP_IDX(i)] = v[i] * cora_gelu_grad(t0[i]);
-        } break;
-        case OUT_GRAD: {
-          float hr[EPB];
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) { t0[i] = 0.f; hr[i] = 0.f; }
-          if (tgt) { EP_FETCH(t0, tgt); }
-          if (hreg) { EP_FETCH(hr, hreg); }
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) {
-            const float h = hr[i];
-            const float sg = (h > 0.f) ? 1.f : ((h < 0.f) ? -1.f : 0.f);
-            const float gv = p.alpha2 * (t0[i] + p.l1 * sg + 2.f * p.l2 * h - v[i]);
-            C[EP_IDX(i)] = gv;
-            red += (double)gv * (double)gv;
-          }
-        } break;
-        case OUT_ATOMIC:
-#pragma unroll
-          for (int i = 0; i < EPB; ++i) if (EP_OK(i)) atomicAdd(&C[EP_IDX(i)], v[i]);
-          break;
-      }
-#undef EP_ROW
-#undef EP_OK
-#undef EP_IDX
-#undef EP_FETCH
-    }
-  }
-  if (p.red) {
-    double tot = block_sum_256(red, red_sh);
-    if (tid == 0) {
-      if (p.mode == OUT_GRAD) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + (bx & 7)], tot);
-      else atomicAdd(&p.red[(long long)g * p.red_stride], tot);
-    }
-  }
+  for (int n = 0; n < 2; ++n) gemm_ep_tile(p, q, acc[n], row0 + 32 * w + 4 * hi, col0 + 32 * n + r, red);
+  gemm_ep_reduce(p, g, bx, red, red_sh);
 }
 
 #ifndef GEMM_WAVES
@@ -339,6 +244,10 @@ static void launch_bk(const GemmP& p, bool ako, bool bko, dim3 grid, hipStream_t
 }
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
+  // bf16 mode, both operands K-inner: the bf16-staged kernel (CORA_BF16_INREG=1 keeps the in-register
+  // conversion of this file, for A/B measurements)
+  static const bool inreg = getenv("CORA_BF16_INREG") != nullptr;
+  if (!a_kouter && !b_kouter && !inreg && gemm_bf16_nt_supported(p)) { launch_gemm_bf16_nt(p, st); return; }
   dim3 grid((p.R + BM - 1) / BM, (p.O + BN - 1) / BN, p.groups * p.splitk);
   const bool bk32 = (p.K % 32 == 0 && p.splitk == 1);
   if (p.bf16 == 2) {

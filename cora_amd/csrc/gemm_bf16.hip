@@ -1,0 +1,206 @@
+// gemm_bf16.hip -- the bf16 mode's grouped GEMM (gfx950): C[R,O] = alpha * A[R,K] * B[O,K]^T + epilogue.
+//
+// Opt-in path (cora_config.dtype_mode = 1; the fp32 kernel of gemm.hip is the parity path).  Everything
+// in HBM stays fp32; operands are rounded to bf16 ONCE, on their way from the staging registers into
+// LDS, so a k-tile costs half the LDS bytes of the fp32 kernel, its fragments are one ds_read_b128 per
+// v_mfma_f32_32x32x16_bf16 operand (8 k values per lane) and no conversion work sits between the
+// MFMAs.  SPLIT = 1 keeps the two-term split x = hi + lo of both operands (three MFMAs, products good
+// to ~2^-16): the forward predictions feed e = h - u, which cancels most of u, and plain bf16 there
+// costs 2.5e-2 on the 6-block vodes (gemm.hip).
+//
+// Both operands are K-inner ("NT"): activations [row][k] and weights [out][in].  The backward-data
+// GEMMs, whose weight is K-outer as stored, read the transposed weight copies the context keeps in
+// bf16 mode (ctx.hip: refresh_wt), so one operand form serves every GEMM of the inference step; the
+// weight-gradient contractions (K-outer on both sides, once per batch) stay on gemm.hip.
+//
+// Tile 128 x 128 x 32, 256 threads = 2 x 2 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator
+// registers): per 16-deep k step a wave reads 2 + 2 fragments for 4 MFMAs (split: 4 + 4 for 12).
+// LDS rows are 32 bf16 + 8 pad = 80 B: the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS)
+// then touch 16 distinct 16-byte slots of the 256-byte bank row.  Workgroup ids are dealt so that each
+// XCD gets a contiguous range with the column tiles of one row tile adjacent: a row tile of A is
+// fetched from HBM once and re-read from that XCD's L2 for the other column tiles.  The output and the
+// read-once epilogue operands are streamed (nontemporal: -5 % over the cfg 4 GEMM set).
+//
+// Measured on the cfg 4 shapes (scripts/gemm_bf16_bench.hip, 8 GEMMs of one inference step, 1 986 us):
+// the MFMA + staging chain alone takes 917 us, global loads add ~580 and the epilogue ~490, largely
+// additively -- with one staging register set a wave that waits for its loads is not multiplying.
+// Tried and dropped: 64-deep k slabs (occupancy 3 -> 2: 2 171 us), 8 waves of 64 x 32 (3 065 us, spills
+// under the 128-register cap), and a producer / consumer split of a 512-thread persistent workgroup
+// with three slabs in flight per producer (2 324 us: the compiler's vmcnt bookkeeping drains every
+// outstanding load at the first use once loads from several loop iterations are in flight, so the
+// deeper prefetch never materialises without hand-written waits).
+#include "common.h"
+#include "gemm_epilogue.h"
+
+#ifndef EP_STREAM
+#define EP_STREAM true
+#endif
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#ifndef BF_TK
+#define BF_TK 32
+#endif
+constexpr int TM = 128, TN = 128, TK = BF_TK;
+#ifndef BF_THREADS
+#define BF_THREADS 256
+#endif
+constexpr int NTHR = BF_THREADS, NWC = NTHR / 128;      // waves across the 128 columns (2 or 4); 2 wave rows of 64
+constexpr int WN = TN / NWC / 32;                        // 32-column MFMA tiles per wave (2 or 1)
+constexpr int KQ = TK / 4, NV = TM * TK / 4 / NTHR, RSTEP = NTHR / KQ;   // staging: float4 per row, per thread and operand, row step
+constexpr int LDR = TK + 8;          // bf16 per LDS row
+
+__device__ __forceinline__ bf16x4 to_bf16(const float4 v) {
+  bf16x4 h;
+  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  return h;
+}
+__device__ __forceinline__ bf16x4 to_bf16_lo(const float4 v, const bf16x4 h) {
+  bf16x4 l;
+  l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+  l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+  return l;
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(NTHR, NTHR / 256 * 2) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
+  __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? TM * LDR : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT ? TN * LDR : 8];
+  __shared__ double red_sh[NTHR / 64];
+
+  // hardware deals consecutive workgroup ids round-robin over the 8 XCDs: XCD x works through the
+  // contiguous range [x * per, (x + 1) * per) of the tile list (column tile fastest)
+  const int per = (ntiles + 7) >> 3;
+  const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (lin >= ntiles) return;
+  const int by = lin % ty, bx = (lin / ty) % tx, g = lin / (ty * tx);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int wr = w / NWC, wc = w % NWC;
+  const int row0 = bx * TM, col0 = by * TN;
+  const float* A = p.A + (long long)g * p.sA;
+  const float* Bw = p.Bw + (long long)g * p.sB;
+
+  // staging: float4 #f of a 128 x TK tile = row f / KQ, k quad f % KQ; thread t takes #t + 256 i (row t / KQ + RSTEP i)
+  const int srow = tid / KQ, skq = tid % KQ;
+  float4 ra[NV], rb[NV];
+  auto load_tiles = [&](int k0) {
+    const int gk = k0 + 4 * skq;
+    const bool kok = gk < p.K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gr = row0 + srow + RSTEP * i;
+      ra[i] = (kok && gr < p.R) ? *reinterpret_cast<const float4*>(A + (long long)gr * p.lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gc = col0 + srow + RSTEP * i;
+      rb[i] = (kok && gc < p.O) ? *reinterpret_cast<const float4*>(Bw + (long long)gc * p.ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float4 v = ra[i];
+      if (p.a_gelu) { v.x = cora_gelu(v.x); v.y = cora_gelu(v.y); v.z = cora_gelu(v.z); v.w = cora_gelu(v.w); }
+      const int o = (srow + RSTEP * i) * LDR + 4 * skq;
+      const bf16x4 h = to_bf16(v);
+      *reinterpret_cast<bf16x4*>(&Ah[o]) = h;
+      if (SPLIT) *reinterpret_cast<bf16x4*>(&Al[o]) = to_bf16_lo(v, h);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 v = rb[i];
+      const int o = (srow + RSTEP * i) * LDR + 4 * skq;
+      const bf16x4 h = to_bf16(v);
+      *reinterpret_cast<bf16x4*>(&Bh[o]) = h;
+      if (SPLIT) *reinterpret_cast<bf16x4*>(&Bl[o]) = to_bf16_lo(v, h);
+    }
+  };
+
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  // lane (r, hi) holds k = 16 kk + 8 hi .. + 7 of its row (A) / column (B): 16 bytes, one ds_read_b128
+  const int aoff = (64 * wr + r) * LDR + 8 * hi;
+  const int boff = (32 * WN * wc + r) * LDR + 8 * hi;
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+    __syncthreads();            // the previous tile is fully consumed
+    store_tiles();
+    __syncthreads();
+    if (k0 + TK < p.K) load_tiles(k0 + TK);     // next tile into registers under the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < TK / 16; ++kk) {
+      bf16x8 ah[2], bh[WN], al[2], bl[WN];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const bf16x8*>(&Ah[aoff + 32 * m * LDR + 16 * kk]);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) bh[n] = *reinterpret_cast<const bf16x8*>(&Bh[boff + 32 * n * LDR + 16 * kk]);
+      if (SPLIT) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) bl[n] = *reinterpret_cast<const bf16x8*>(&Bl[boff + 32 * n * LDR + 16 * kk]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);   // small terms first
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  const GemmEp q = gemm_ep_ptrs(p, g);
+  double red = 0.0;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+      gemm_ep_tile<EP_STREAM>(p, q, acc[m][n], row0 + 64 * wr + 32 * m + 4 * hi, col0 + 32 * WN * wc + 32 * n + r, red);
+  if (p.red) {      // energy / sum of squares of the whole workgroup (OUT_GRAD: 8 slots per vode, folded on the host)
+    const double wsum = wave_sum_d(red);
+    if (lane == 0) red_sh[w] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NTHR / 64; ++k) tot += red_sh[k];
+      if (p.mode == OUT_GRAD) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + (bx & 7)], tot);
+      else atomicAdd(&p.red[(long long)g * p.red_stride], tot);
+    }
+  }
+}
+
+}  // namespace
+
+bool gemm_bf16_nt_supported(const GemmP& p) {
+  return p.bf16 != 0 && p.splitk == 1 && !p.b_gelu && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+         (p.sA % 4) == 0 && (p.sB % 4) == 0;
+}
+
+void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st) {
+  const int tx = (p.R + TM - 1) / TM, ty = (p.O + TN - 1) / TN;
+  const int ntiles = tx * ty * p.groups;
+  const dim3 grid(((ntiles + 7) / 8) * 8);
+  if (p.bf16 == 2) hipLaunchKernelGGL((gemm_bf16_nt_kernel<1>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+  else hipLaunchKernelGGL((gemm_bf16_nt_kernel<0>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+}
