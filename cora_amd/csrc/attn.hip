@@ -55,8 +55,10 @@ __device__ __forceinline__ void load_frag(float* f, const float* src, int ld, in
   for (int s = 0; s < DH / 4; ++s) f[s] = (row < nrows) ? src[(long long)row * ld + 4 * s + grp] : 0.f;
 }
 
-// S[tt] (tt = 0..3) = streamed rows 16tt..16tt+15 (from LDS) x own fragment
-template <int DH>
+// S[tt] (tt = 0..NVT-1) = streamed rows 16tt..16tt+15 (from LDS) x own fragment.  NVT = 16-row tiles of
+// the chunk that hold a valid row: the ragged last chunk of a sequence (N = 196: 4 of 64 rows) skips
+// the MFMAs of its empty tiles instead of multiplying padding.
+template <int DH, int NVT = 4>
 __device__ __forceinline__ void score_tiles(f32x4* S, const float* lds, const float* frag, int c, int grp) {
   constexpr int LD = DH + 4;
 #pragma unroll
@@ -65,16 +67,16 @@ __device__ __forceinline__ void score_tiles(f32x4* S, const float* lds, const fl
   for (int s = 0; s < DH / 4; ++s) {
     float b = frag[s];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) S[tt] = mfma16(lds[(16 * tt + c) * LD + 4 * s + grp], b, S[tt]);
+    for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(lds[(16 * tt + c) * LD + 4 * s + grp], b, S[tt]);
   }
 }
 
 // acc[ct] (ct = 0..DH/16-1) += sum over the 64 streamed rows of Z[row][16ct + c] * Pv[row][own]
-template <int DH>
+template <int DH, int NVT = 4>
 __device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const f32x4* Pv, int c, int grp) {
   constexpr int LD = DH + 4;
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt)
+  for (int tt = 0; tt < NVT; ++tt)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       float b = Pv[tt][reg];
@@ -82,6 +84,16 @@ __device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const 
 #pragma unroll
       for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = mfma16(zr[16 * ct], b, acc[ct]);
     }
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+// run body(IntC<nvt>) for nvt = 1..4 valid 16-row tiles in the streamed chunk (uniform over the workgroup)
+template <typename F>
+__device__ __forceinline__ void for_valid_tiles(int nvt, F&& body) {
+  if (nvt >= 4) body(IntC<4>{});
+  else if (nvt == 3) body(IntC<3>{});
+  else if (nvt == 2) body(IntC<2>{});
+  else body(IntC<1>{});
 }
 
 __device__ __forceinline__ float grp_max(float v) {
@@ -118,41 +130,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int ct = 0; ct < NT16(DH); ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
 
+  // a wave whose 16 query rows all lie past the sequence (the last row block of N = 196 holds 4 rows)
+  // only helps staging; empty key tiles of the last chunk are skipped (for_valid_tiles)
+  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
     stage_rows<DH>(sm.s1, K, ld, k0, N);
     stage_rows<DH>(sm.s2, V, ld, k0, N);
     __syncthreads();
-    f32x4 S[4];
-    score_tiles<DH>(S, sm.s1, qf, c, grp);
-    float mx = -INFINITY;
+    if (!wave_active) continue;
+    for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
+      constexpr int NVT = decltype(nv)::value;
+      f32x4 S[4];
+      score_tiles<DH, NVT>(S, sm.s1, qf, c, grp);
+      float mx = -INFINITY;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NVT; ++tt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        int key = k0 + 16 * tt + 4 * grp + reg;
-        float s = (key < N) ? S[tt][reg] * sc : -INFINITY;
-        S[tt][reg] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = grp_max(mx);
-    float mnew = fmaxf(m, mx);               // finite: every chunk holds at least one valid key
-    float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    float ps = 0.f;
+        for (int reg = 0; reg < 4; ++reg) {
+          int key = k0 + 16 * tt + 4 * grp + reg;
+          float sv = (key < N) ? S[tt][reg] * sc : -INFINITY;
+          S[tt][reg] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      mx = grp_max(mx);
+      float mnew = fmaxf(m, mx);               // finite: every chunk holds at least one valid key
+      float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      float ps = 0.f;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NVT; ++tt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float pv = __builtin_amdgcn_exp2f(S[tt][reg] - mnew);
-        S[tt][reg] = pv;
-        ps += pv;
-      }
-    ps = grp_sum(ps);
-    lsum = lsum * alpha + ps;
-    m = mnew;
+        for (int reg = 0; reg < 4; ++reg) {
+          float pv = __builtin_amdgcn_exp2f(S[tt][reg] - mnew);
+          S[tt][reg] = pv;
+          ps += pv;
+        }
+      ps = grp_sum(ps);
+      lsum = lsum * alpha + ps;
+      m = mnew;
 #pragma unroll
-    for (int ct = 0; ct < NT16(DH); ++ct) oacc[ct] *= alpha;
-    accum_tiles<DH>(oacc, sm.s2, S, c, grp);
+      for (int ct = 0; ct < NT16(DH); ++ct) oacc[ct] *= alpha;
+      accum_tiles<DH, NVT>(oacc, sm.s2, S, c, grp);
+    });
   }
   if (qrow < N) {
     float inv = 1.0f / lsum;
@@ -204,23 +223,28 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 #pragma unroll
   for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
     stage_rows<DH>(sm.s1, K, ld, k0, N);
     stage_rows<DH>(sm.s2, V, ld, k0, N);
     __syncthreads();
-    f32x4 S[4], dP[4];
-    score_tiles<DH>(S, sm.s1, qf, c, grp);
-    score_tiles<DH>(dP, sm.s2, dof, c, grp);
+    if (!wave_active) continue;
+    for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
+      constexpr int NVT = decltype(nv)::value;
+      f32x4 S[4], dP[4];
+      score_tiles<DH, NVT>(S, sm.s1, qf, c, grp);
+      score_tiles<DH, NVT>(dP, sm.s2, dof, c, grp);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NVT; ++tt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        int key = k0 + 16 * tt + 4 * grp + reg;
-        float pv = (key < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - l2) : 0.f;
-        S[tt][reg] = pv * (dP[tt][reg] - dl);  // dS
-      }
-    accum_tiles<DH>(acc, sm.s1, S, c, grp);  // dQ^T += K^T dS^T
+        for (int reg = 0; reg < 4; ++reg) {
+          int key = k0 + 16 * tt + 4 * grp + reg;
+          float pv = (key < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - l2) : 0.f;
+          S[tt][reg] = pv * (dP[tt][reg] - dl);  // dS
+        }
+      accum_tiles<DH, NVT>(acc, sm.s1, S, c, grp);  // dQ^T += K^T dS^T
+    });
   }
   if (qrow < N) {
     float* drow = dqkv + ((long long)img * N + qrow) * ld + h * DH;
@@ -261,6 +285,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
   for (int q0 = 0; q0 < N; q0 += CH) {
     __syncthreads();
     stage_rows<DH>(sm.s1, Q, ld, q0, N);
@@ -272,20 +297,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
       sm.rowc[CH + threadIdx.x] = (q < N) ? delta[ri] : 0.f;
     }
     __syncthreads();
-    f32x4 S[4], dP[4];
-    score_tiles<DH>(S, sm.s1, kf, c, grp);   // S[q][key]
-    score_tiles<DH>(dP, sm.s2, vf, c, grp);  // dP[q][key] = dO[q] . V[key]
+    if (!wave_active) continue;
+    for_valid_tiles((N - q0 + 15) >> 4, [&](auto nv) {
+      constexpr int NVT = decltype(nv)::value;
+      f32x4 S[4], dP[4];
+      score_tiles<DH, NVT>(S, sm.s1, kf, c, grp);   // S[q][key]
+      score_tiles<DH, NVT>(dP, sm.s2, vf, c, grp);  // dP[q][key] = dO[q] . V[key]
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NVT; ++tt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        int ql = 16 * tt + 4 * grp + reg;
-        float pv = (q0 + ql < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - sm.rowc[ql]) : 0.f;
-        S[tt][reg] = pv;                                        // P
-        dP[tt][reg] = pv * (dP[tt][reg] - sm.rowc[CH + ql]);    // dS
-      }
-    accum_tiles<DH>(dv, sm.s2, S, c, grp);   // dV^T += dO^T P
-    accum_tiles<DH>(dk, sm.s1, dP, c, grp);  // dK^T += Q^T dS
+        for (int reg = 0; reg < 4; ++reg) {
+          int ql = 16 * tt + 4 * grp + reg;
+          float pv = (q0 + ql < N) ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - sm.rowc[ql]) : 0.f;
+          S[tt][reg] = pv;                                        // P
+          dP[tt][reg] = pv * (dP[tt][reg] - sm.rowc[CH + ql]);    // dS
+        }
+      accum_tiles<DH, NVT>(dv, sm.s2, S, c, grp);   // dV^T += dO^T P
+      accum_tiles<DH, NVT>(dk, sm.s1, dP, c, grp);  // dK^T += Q^T dS
+    });
   }
   if (krow < N) {
     float* drow = dqkv + ((long long)img * N + krow) * ld + h * DH;
