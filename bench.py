@@ -305,13 +305,21 @@ def offline_traffic(roof, cfg_name, B, over):
     """HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (scripts/pmc_traffic.sh), committed under profiles/.  FETCH_SIZE reads 1/2 of wide coalesced reads on
     gfx950 (MI355X_MICROARCH.md, HBM) -> doubled; both counters are in KB.  Offline: not measured in this run."""
-    for fn in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    if over or B != 200 or roof.get("kernel") != "pc_block_fused":
+        return
+    # (file, kernel-name prefix) per benchmarked configuration
+    table = {"6block": (("r2_pmc_traffic.json", "r1_pmc_traffic.json"), "void pc_block_fused_kernel<0"),
+             "12block": (("r2_pmc_traffic_12block.json",), "void pc_block_wide2_kernel")}
+    if cfg_name not in table:
+        return
+    files, prefix = table[cfg_name]
+    for fn in files:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
             continue
-        key = next((k for k in tj if roof.get("kernel") == "pc_block_fused" and k.startswith("void pc_block_fused_kernel<0")), None)
-        if key and cfg_name == "6block" and B == 200 and not over and "WRITE_SIZE_per_launch_KB" in tj[key]:
+        key = next((k for k in tj if k.startswith(prefix)), None)
+        if key and "WRITE_SIZE_per_launch_KB" in tj[key] and "FETCH_SIZE_per_launch_KB" in tj[key]:
             roof["traffic"] = 1024.0 * (2.0 * tj[key]["FETCH_SIZE_per_launch_KB"] + tj[key]["WRITE_SIZE_per_launch_KB"])
             roof["traffic_source"] = f"profiles/{fn} (rocprofv3 PMC, offline)"
             return
@@ -391,6 +399,7 @@ def main():
         }
         if extra is not None:
             extra.pop("mc"); extra.pop("tc")
+            offline_traffic(extra["roofline"], "12block", B, {})
             result["extra"] = {"cfg3": {k: extra[k] for k in (
                 "workload", "value", "ms_per_step", "steps", "warmup", "whole_step_mfma_frac", "roofline",
                 "infer_only_images_steps_per_s", "algorithmic_flops_per_image_step", "kernel_ms_per_inference_step",
