@@ -340,6 +340,12 @@ def main():
     if args.dry_run_launch:
         return dry_run_rank(args, rank, world)
 
+    # stdout carries exactly ONE line, the JSON result: libraries that print from C (RCCL's version banner at
+    # communicator creation goes to stdout) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import cora_amd as ca
     if not torch.cuda.is_available():
@@ -410,7 +416,8 @@ def main():
             result["cpu_baseline"] = None
         if "CORA_HIP_LIB" in os.environ:    # not a product number: the library was swapped for a diagnostic build
             result["diagnostic_library"] = os.environ["CORA_HIP_LIB"]
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -151,6 +151,7 @@ struct cora_ctx {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   bool dist_warm = false;
+  bool dist_graph_broken = false;   // a collective could not be captured: cora_step_dist stays on eager launches
   std::map<int, hipGraphExec_t> dist_graphs;   // key 2 T + exact_clip: T-step loop (+ per-step sum-of-squares all-reduce)
   hipGraphExec_t dist_learn_graph = nullptr;   // wgrad, all-reduce of dE/dW, clip + AdamW, reconstruction
   float apply_graph_scale = 0.f;   // cora_step: weight gradients + AdamW + reconstruction, captured once
@@ -1598,42 +1599,49 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
   HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
   HCHECK(hipMemcpyAsync(c->hyp_dev, hy, sizeof(float) * 4, hipMemcpyHostToDevice, c->st));
   c->last_T = T;
-  const bool graphed = c->use_graph && !c->prof && c->dist_warm;
+  static const bool no_dist_graph = getenv("CORA_DIST_NO_GRAPH") != nullptr;   // operator switch: eager collectives
+  bool graphed = c->use_graph && !c->prof && c->dist_warm && !c->dist_graph_broken && !no_dist_graph;
+  hipGraphExec_t infer_exec = nullptr;
+  if (graphed) {
+    // Build the two graphs if they are missing.  Capturing only records: if RCCL (or HIP) refuses a
+    // collective under stream capture on this system, nothing has run, every rank sees the same refusal
+    // at the same call, and the step falls back -- for good -- to the eager launch sequence of the
+    // first call, which is known to work by then.
+    auto capture = [&](auto&& enqueue, hipGraphExec_t* exec) -> bool {
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
+      const int rce = enqueue();
+      const hipError_t e = hipStreamEndCapture(c->st, &graph);
+      bool ok = (rce == 0 && e == hipSuccess && graph != nullptr);
+      if (ok) ok = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (!ok) (void)hipGetLastError();
+      return ok;
+    };
+    const int key = 2 * T + (exact ? 1 : 0);
+    auto it = c->dist_graphs.find(key);
+    if (it == c->dist_graphs.end()) {
+      hipGraphExec_t exec = nullptr;
+      if (capture([&]() { return enqueue_infer_dist(c, T, exact); }, &exec)) { c->dist_graphs[key] = exec; it = c->dist_graphs.find(key); }
+      else graphed = false;
+    }
+    if (graphed && !c->dist_learn_graph && !capture([&]() { return enqueue_learn_dist(c); }, &c->dist_learn_graph)) {
+      c->dist_learn_graph = nullptr;
+      graphed = false;
+    }
+    if (graphed) infer_exec = it->second;
+    else c->dist_graph_broken = true;
+  }
   if (!graphed) {
-    // first call (and CORA_NO_GRAPH): eager launches -- every kernel and every collective runs once
-    // outside stream capture (RCCL sets up its channels and buffers on first use)
+    // first call (and CORA_NO_GRAPH, and after a refused capture): eager launches -- every kernel and
+    // every collective runs outside stream capture (RCCL sets up its channels and buffers on first use)
     HCHECK(hipEventRecord(c->ev0, c->st));
     if ((rc = enqueue_infer_dist(c, T, exact))) return rc;
     HCHECK(hipEventRecord(c->ev1, c->st));
     if ((rc = enqueue_learn_dist(c))) return rc;
   } else {
-    const int key = 2 * T + (exact ? 1 : 0);
-    auto it = c->dist_graphs.find(key);
-    if (it == c->dist_graphs.end()) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed));
-      rc = enqueue_infer_dist(c, T, exact);
-      hipError_t e = hipStreamEndCapture(c->st, &graph);
-      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
-      HCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
-      c->dist_graphs[key] = exec;
-      it = c->dist_graphs.find(key);
-    }
-    if (!c->dist_learn_graph) {
-      hipGraph_t graph = nullptr;
-      HCHECK(hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed));
-      rc = enqueue_learn_dist(c);
-      hipError_t e = hipStreamEndCapture(c->st, &graph);
-      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-      if (e != hipSuccess) FAIL(-2, std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
-      HCHECK(hipGraphInstantiate(&c->dist_learn_graph, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
-    }
     HCHECK(hipEventRecord(c->ev0, c->st));
-    HCHECK(hipGraphLaunch(it->second, c->st));
+    HCHECK(hipGraphLaunch(infer_exec, c->st));
     HCHECK(hipEventRecord(c->ev1, c->st));
     HCHECK(hipGraphLaunch(c->dist_learn_graph, c->st));
   }

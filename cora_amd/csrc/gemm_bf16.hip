@@ -64,13 +64,15 @@ __device__ __forceinline__ bf16x4 to_bf16_lo(const float4 v, const bf16x4 h) {
   return l;
 }
 
+#ifndef BF_OCC
+#define BF_OCC 2
+#endif
 template <int SPLIT>
-__global__ __launch_bounds__(NTHR, NTHR / 256 * 2) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
+__global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
   __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? TM * LDR : 8];
   __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT ? TN * LDR : 8];
-  __shared__ double red_sh[NTHR / 64];
 
   // hardware deals consecutive workgroup ids round-robin over the 8 XCDs: XCD x works through the
   // contiguous range [x * per, (x + 1) * per) of the tile list (column tile fastest)
@@ -177,7 +179,9 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * 2) void gemm_bf16_nt_kernel(cons
     for (int n = 0; n < WN; ++n)
       gemm_ep_tile<EP_STREAM>(p, q, acc[m][n], row0 + 64 * wr + 32 * m + 4 * hi, col0 + 32 * WN * wc + 32 * n + r, red);
   if (p.red) {      // energy / sum of squares of the whole workgroup (OUT_GRAD: 8 slots per vode, folded on the host)
+    double* red_sh = reinterpret_cast<double*>(Ah);      // the tiles are dead: their memory carries the wave sums
     const double wsum = wave_sum_d(red);
+    __syncthreads();                                      // every wave is past its last fragment read
     if (lane == 0) red_sh[w] = wsum;
     __syncthreads();
     if (tid == 0) {
