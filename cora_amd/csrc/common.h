@@ -228,6 +228,9 @@ int launch_fused_wide(const FusedP& p, int L, int D, hipStream_t st);
 // two workgroups per CU (fused_wide2.hip): D = 128, heads of 32; also uses S_dqkv as a dk | dv stash
 bool fused_wide2_supported(int N, int P, int D, int H, int M);
 int launch_fused_wide2(const FusedP& p, int L, hipStream_t st);
+// status-"forward" walk of one image per workgroup through all L blocks (D = 128, heads of 32); in place when
+// stride == 0 and xin == xout, else block g's output goes to xout + g * stride
+int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st);
 void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
 size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

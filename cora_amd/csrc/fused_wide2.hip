@@ -139,6 +139,68 @@ __device__ __forceinline__ void store_slice(const float* f, float* base, int grp
 #define W2STAMP(K) do {} while (0)
 #endif
 
+// ---- weight tile pipeline (shared by the block body and the chain body below) -----------------------
+// The macros name locals both bodies define: tile_src (tile index -> source pointer and row stride), the
+// staging registers sr0..sr3, trow / tcol, wbuf, slot, NT (tiles this workgroup walks through) and the
+// tile geometry constants.
+#define PF_ONE(J, REG, SRC, LDW) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
+#define PB_ONE(J, REG, WB) lds_st4((WB) + 8 * (J) * LD, REG);
+#define PREFETCH_ALL(K)                                                                           \
+  do {                                                                                            \
+    int ld_; const float* s_ = tile_src((K), ld_);                                                \
+    PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
+  } while (0)
+#define WRITE_ALL(S)                                                                              \
+  do {                                                                                            \
+    lds_float* wb_ = opaque_w(wbuf + (S) * SLOT + trow * LD + tcol);                              \
+    PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
+  } while (0)
+  // column group C of the multiplication with tile k; the even groups carry one staged float4 each
+#define GEMM_CT(C, XF, ACC)                                                                       \
+  {                                                                                               \
+    if ((C) + 1 < NCT) {                                                                          \
+      _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot)                                          \
+        a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
+    if ((C) == 0) { if (do_w_) { PB_ONE(0, sr0, wb_) } if (do_p_) { PF_ONE(0, sr0, ns_, nld_) } } \
+    if ((C) == 2) { if (do_w_) { PB_ONE(1, sr1, wb_) } if (do_p_) { PF_ONE(1, sr1, ns_, nld_) } } \
+    if ((C) == 4) { if (do_w_) { PB_ONE(2, sr2, wb_) } if (do_p_) { PF_ONE(2, sr2, ns_, nld_) } } \
+    if ((C) == 6) { if (do_w_) { PB_ONE(3, sr3, wb_) } if (do_p_) { PF_ONE(3, sr3, ns_, nld_) } } \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].w, (XF)[4 * (C) + 3], (ACC)[ot]); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+#define STAGE(K, XF, ACC)                                                                         \
+  do {                                                                                            \
+    const int k_ = (K);                                                                           \
+    const bool do_w_ = (k_ + 1 < NT);                                                             \
+    const bool do_p_ = (k_ + 2 < NT);                                                             \
+    int nld_ = D; const float* ns_ = do_p_ ? tile_src(k_ + 2, nld_) : nullptr;                    \
+    __syncthreads();                                                                              \
+    const lds_float* tl_ = opaque(wbuf + slot * SLOT + i * LD + 4 * grp);                         \
+    lds_float* wb_ = opaque_w(wbuf + (slot ^ 1) * SLOT + trow * LD + tcol);                       \
+    float4 a_[2][NOT];                                                                            \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
+    GEMM_CT(0, XF, ACC) GEMM_CT(1, XF, ACC) GEMM_CT(2, XF, ACC) GEMM_CT(3, XF, ACC)               \
+    GEMM_CT(4, XF, ACC) GEMM_CT(5, XF, ACC) GEMM_CT(6, XF, ACC) GEMM_CT(7, XF, ACC)               \
+    slot ^= 1;                                                                                    \
+    (void)wb_; (void)ns_; (void)nld_;                                                             \
+  } while (0)
+// one GEMM with D outputs: NQ stages, quarter j -> registers [8 j, 8 j + 8) of OUT
+#define GEMM_D(K0, XF, OUT)                                                                       \
+  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) {                                             \
+    f32x4 acc_[NOT]; zero_acc<NOT>(acc_);                                                         \
+    STAGE((K0) + j_, XF, acc_);                                                                   \
+    unpack_at<NOT>(acc_, OUT, NOT * j_);                                                          \
+  }
+// the same, accumulating into ACCD[NCT] over several K-chunks
+#define GEMM_D_ACC(K0, XF, ACCD)                                                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) STAGE((K0) + j_, XF, (ACCD) + NOT * j_);
+
+
 template <int NCT, int H>
 __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, int g, int b) {
   constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
@@ -227,64 +289,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   };
   const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
   float4 sr0, sr1, sr2, sr3;
-#define PF_ONE(J, REG, SRC, LDW) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
-#define PB_ONE(J, REG, WB) lds_st4((WB) + 8 * (J) * LD, REG);
-#define PREFETCH_ALL(K)                                                                           \
-  do {                                                                                            \
-    int ld_; const float* s_ = tile_src((K), ld_);                                                \
-    PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
-  } while (0)
-#define WRITE_ALL(S)                                                                              \
-  do {                                                                                            \
-    lds_float* wb_ = opaque_w(wbuf + (S) * SLOT + trow * LD + tcol);                              \
-    PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
-  } while (0)
-  // column group C of the multiplication with tile k; the even groups carry one staged float4 each
-#define GEMM_CT(C, XF, ACC)                                                                       \
-  {                                                                                               \
-    if ((C) + 1 < NCT) {                                                                          \
-      _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot)                                          \
-        a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
-    }                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
-    if ((C) == 0) { if (do_w_) { PB_ONE(0, sr0, wb_) } if (do_p_) { PF_ONE(0, sr0, ns_, nld_) } } \
-    if ((C) == 2) { if (do_w_) { PB_ONE(1, sr1, wb_) } if (do_p_) { PF_ONE(1, sr1, ns_, nld_) } } \
-    if ((C) == 4) { if (do_w_) { PB_ONE(2, sr2, wb_) } if (do_p_) { PF_ONE(2, sr2, ns_, nld_) } } \
-    if ((C) == 6) { if (do_w_) { PB_ONE(3, sr3, wb_) } if (do_p_) { PF_ONE(3, sr3, ns_, nld_) } } \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].w, (XF)[4 * (C) + 3], (ACC)[ot]); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-  }
   int slot = 0;
-#define STAGE(K, XF, ACC)                                                                         \
-  do {                                                                                            \
-    const int k_ = (K);                                                                           \
-    const bool do_w_ = (k_ + 1 < NT);                                                             \
-    const bool do_p_ = (k_ + 2 < NT);                                                             \
-    int nld_ = D; const float* ns_ = do_p_ ? tile_src(k_ + 2, nld_) : nullptr;                    \
-    __syncthreads();                                                                              \
-    const lds_float* tl_ = opaque(wbuf + slot * SLOT + i * LD + 4 * grp);                         \
-    lds_float* wb_ = opaque_w(wbuf + (slot ^ 1) * SLOT + trow * LD + tcol);                       \
-    float4 a_[2][NOT];                                                                            \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
-    GEMM_CT(0, XF, ACC) GEMM_CT(1, XF, ACC) GEMM_CT(2, XF, ACC) GEMM_CT(3, XF, ACC)               \
-    GEMM_CT(4, XF, ACC) GEMM_CT(5, XF, ACC) GEMM_CT(6, XF, ACC) GEMM_CT(7, XF, ACC)               \
-    slot ^= 1;                                                                                    \
-    (void)wb_; (void)ns_; (void)nld_;                                                             \
-  } while (0)
   static_assert(NCT == 8, "GEMM_CT is written out for 8 column groups");
-  // one GEMM with D outputs: NQ stages, quarter j -> registers [8 j, 8 j + 8) of OUT
-#define GEMM_D(K0, XF, OUT)                                                                       \
-  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) {                                             \
-    f32x4 acc_[NOT]; zero_acc<NOT>(acc_);                                                         \
-    STAGE((K0) + j_, XF, acc_);                                                                   \
-    unpack_at<NOT>(acc_, OUT, NOT * j_);                                                          \
-  }
-  // the same, accumulating into ACCD[NCT] over several K-chunks
-#define GEMM_D_ACC(K0, XF, ACCD)                                                                  \
-  _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) STAGE((K0) + j_, XF, (ACCD) + NOT * j_);
 
   PREFETCH_ALL(0);
   WRITE_ALL(0);                    // tile 0 -> slot 0 (visible after stage 0's barrier)
@@ -529,14 +535,171 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     store_row<NCT>(dy, p.BP1 + (long long)g * nl + rowoff, grp);
     W2STAMP(13);
   }
-#undef STAGE
-#undef GEMM_CT
-#undef GEMM_D
-#undef GEMM_D_ACC
-#undef PREFETCH_ALL
-#undef WRITE_ALL
-#undef PF_ONE
-#undef PB_ONE
+}
+
+// ---- chain: status "forward" (/root/reference/src/decoder_transformer.py:232-241, 488-494) -------------
+// One workgroup walks ONE image through all L blocks: x_{g+1} = u_{g+2}(x_g) = 2 x + MHA(LN1 x) + MLP(LN2(...)),
+// the forward half of the block body on the same weight-tile pipeline (12 NQ = 48 tiles per block, the
+// prefetch running across block boundaries).  Used for the INIT pass (every u stored as the next vode) and
+// for the reconstruction after the weight update; replaces 7 launches per block on the per-op kernels
+// (12 800-row GEMMs that fill the chip for 12..35 us each, 84 launches and their gaps: 1.8 ms at L = 12).
+// Block g reads its rows from (g == 0 ? xin : xout + (g - 1) stride) and writes them to xout + g stride;
+// with stride = 0 and xin == xout the walk is in place (a lane re-reads only rows it wrote itself).
+template <int NCT, int H>
+__device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, int b, const float* xin, float* xout, long long stride) {
+  constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
+  constexpr int NOT = 2, TR = 32;
+  constexpr int NQ = D / TR;
+  constexpr int LD = D + 4, SLOT = TR * LD;
+  constexpr int DH = D / H, NCH = DH / 16, RH = 4 * NCH;
+  constexpr int LDH = DH + 4, HT = 64 * LDH;
+  constexpr int LDT = 64 + 4;
+  constexpr int TPB = 12 * NQ;                    // forward tiles per block (48)
+  static_assert(DH == 32 && NCT == 8, "built for D = 128, heads of 32");
+  const int NT = TPB * p.L;
+  const float sc = rsqrtf((float)DH) * CORA_LOG2E;
+
+  float* wbuf = lds;
+  float* tA = lds + 2 * SLOT;
+  float* tB = tA + HT;
+  float* tC = tB + HT;
+  float* tD = tC + HT;
+  float* pb = tD + HT + 2 * H * 64;      // same carve-up as the block body: [b1 M | ln2 gamma D | ln2 beta D | b2 D]
+  constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;
+
+  auto tile_src = [&](int k, int& ldw) -> const float* {
+    const int gg = k / TPB, kk = k - gg * TPB;
+    if (kk < 3 * NQ) { ldw = D; return p.W + p.oWqkv + (long long)gg * 3 * D * D + (long long)kk * TR * D; }
+    if (kk < 4 * NQ) { ldw = D; return p.W + p.oWo + (long long)gg * D * D + (long long)(kk - 3 * NQ) * TR * D; }
+    const int mt = (kk - 4 * NQ) / (2 * NQ), j = (kk - 4 * NQ) % (2 * NQ);
+    if (j < NQ) { ldw = D; return p.W + p.oW1 + (long long)gg * M * D + ((long long)mt * D + j * TR) * D; }
+    ldw = M; return p.W + p.oW2 + (long long)gg * D * M + (long long)(j - NQ) * TR * M + (long long)mt * D;
+  };
+  const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
+  float4 sr0, sr1, sr2, sr3;
+  int slot = 0;
+  PREFETCH_ALL(0);
+  WRITE_ALL(0);
+  PREFETCH_ALL(1);
+
+  for (int g = 0; g < p.L; ++g) {
+    const float* xrow = (g == 0 ? xin : xout + (long long)(g - 1) * stride) + rowoff;
+    float* urow = xout + (long long)g * stride + rowoff;
+    const int k0 = g * TPB;
+    __syncthreads();                     // the previous block's parameter vectors and head tiles are no longer read
+    {
+      constexpr int NP4 = (M + 3 * D) / 4;
+      for (int f = tid; f < NP4; f += 256) {
+        const int o = 4 * f;
+        const float* src = o < M ? p.W + p.ob1 + (long long)g * M + o
+                         : o < M + D ? p.W + p.oLn2g + (long long)g * D + (o - M)
+                         : o < M + 2 * D ? p.W + p.oLn2b + (long long)g * D + (o - M - D)
+                                         : p.W + p.ob2 + (long long)g * D + (o - M - 2 * D);
+        *reinterpret_cast<float4*>(pb + o) = *reinterpret_cast<const float4*>(src);   // visible after the next tile barrier
+      }
+    }
+    float y[R];
+    {
+      float q[R], kk[R], v[R];
+      {
+        float xn[R];
+        {
+          float x[R], gm[R], bt[R], xh[R + 1];
+          load_row<NCT>(x, xrow, grp);
+          load_row<NCT>(gm, p.W + p.oLn1g + (long long)g * D, grp);
+          load_row<NCT>(bt, p.W + p.oLn1b + (long long)g * D, grp);
+          ln_row<NCT>(x, gm, bt, xh, xn);
+        }
+        GEMM_D(k0, xn, q)
+        GEMM_D(k0 + NQ, xn, kk)
+        GEMM_D(k0 + 2 * NQ, xn, v)
+      }
+      float of[R];
+#pragma unroll
+      for (int hp = 0; hp < H; hp += 2) {
+        __syncthreads();                 // the previous round's tiles are no longer read
+        put_slice<LDH, NCH>(kk + RH * hp, tA, w, i, grp);
+        put_slice_t<LDT, NCH>(v + RH * hp, tB, w, i, grp);
+        put_slice<LDH, NCH>(kk + RH * (hp + 1), tC, w, i, grp);
+        put_slice_t<LDT, NCH>(v + RH * (hp + 1), tD, w, i, grp);
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int h = hp + hh;
+          const float* tK = hh ? tC : tA;
+          const float* tV = hh ? tD : tB;
+          f32x4 sa[4];
+          zero_acc<4>(sa);
+          gemm_hd<LDH, NCH>(tK, q + RH * h, sa, i, grp);           // S[key][q]
+          float pf[16];
+          unpack_at<4>(sa, pf, 0);
+          float mx = -INFINITY;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
+          mx = grp_max(mx);
+          float ls = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
+          ls = grp_sum(ls);
+          const float inv = 1.0f / ls;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) pf[k] *= inv;
+          accum_t<LDT, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);    // O, this head's columns
+        }
+      }
+      GEMM_D(k0 + 3 * NQ, of, y)           // y = x + att Wo^T
+      {
+        float x[R];
+        load_row<NCT>(x, xrow, grp);
+#pragma unroll
+        for (int k = 0; k < R; ++k) y[k] += x[k];
+      }
+    }
+    float zn[R], xr[R];
+    {
+      float gm[R], bt[R], xh[R + 1];
+      load_row<NCT>(gm, pb + PB_LN2G, grp);
+      load_row<NCT>(bt, pb + PB_LN2B, grp);
+      ln_row<NCT>(y, gm, bt, xh, zn);
+    }
+    f32x4 zacc[NCT];
+    zero_acc<NCT>(zacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float am[R];
+      GEMM_D(k0 + 4 * NQ + 2 * NQ * mt, zn, am)
+      {
+        float b1[R];
+        load_row<NCT>(b1, pb + mt * D, grp);
+#pragma unroll
+        for (int k = 0; k < R; k += 2) {
+          f32x2 g2, gp2;
+          cora_gelu_both2((f32x2){am[k] + b1[k], am[k + 1] + b1[k + 1]}, g2, gp2);
+          am[k] = g2.x; am[k + 1] = g2.y;
+        }
+      }
+      if (mt == 3) load_row<NCT>(xr, xrow, grp);     // x again: its latency runs under the last four tiles
+      GEMM_D_ACC(k0 + 5 * NQ + 2 * NQ * mt, am, zacc)
+    }
+    {
+      float z[R], b2[R];
+      unpack_at<NCT>(zacc, z, 0);
+      load_row<NCT>(b2, pb + PB_B2, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) z[k] += xr[k] + y[k] + b2[k];      // u = x + y + MLP
+      store_row<NCT>(z, urow, grp);
+    }
+  }
+}
+
+template <int NCT, int H>
+__global__ __launch_bounds__(256, 1) void pc_chain_wide2_kernel(FusedP p, const float* xin, float* xout, long long stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  wide2_chain_body<NCT, H>(p, lds, (int)blockIdx.x, xin, xout, stride);
 }
 
 template <int NCT, int H>
@@ -566,3 +729,24 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
   hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
+
+// the L blocks of the status-"forward" chain for every image (see wide2_chain_body)
+int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st) {
+  static bool attr[64] = {};
+  constexpr int NCT = 8, H = 4, D = 128, M = 512;
+  const size_t sm = (size_t)(2 * 32 * (D + 4) + 4 * 64 * 36 + 2 * H * 64 + M + 4 * D) * sizeof(float);
+  if (L < 1 || p.L != L) return -1;
+  if (first_use_on_device(attr)) {
+    if (hipFuncSetAttribute((const void*)pc_chain_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL((pc_chain_wide2_kernel<NCT, H>), dim3(p.B), dim3(256), sm, st, p, xin, xout, stride);
+  return 0;
+}
+#undef STAGE
+#undef GEMM_CT
+#undef GEMM_D
+#undef GEMM_D_ACC
+#undef PREFETCH_ALL
+#undef WRITE_ALL
+#undef PF_ONE
+#undef PB_ONE
