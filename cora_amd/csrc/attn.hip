@@ -48,11 +48,38 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld,
   }
 }
 
-// own-row fragment: f[s] = X[row][4s+grp]
+// own-row fragment.  Which k an MFMA step contracts is free as long as the A lane and the B lane agree,
+// so for head dims that are a multiple of 16 step (j, t) takes k = 16 j + 4 grp + t: a lane's fragment is
+// DH/16 contiguous float4 (f[4 j + t] = X[row][16 j + 4 grp + t]) and the streamed side reads one
+// ds_read_b128 per four MFMAs.  Other head dims (24) keep k = 4 s + grp (f[s] = X[row][4 s + grp]).
 template <int DH>
 __device__ __forceinline__ void load_frag(float* f, const float* src, int ld, int row, int nrows, int grp) {
+  if constexpr (DH % 16 == 0) {
 #pragma unroll
-  for (int s = 0; s < DH / 4; ++s) f[s] = (row < nrows) ? src[(long long)row * ld + 4 * s + grp] : 0.f;
+    for (int j = 0; j < DH / 16; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) v = *reinterpret_cast<const float4*>(src + (long long)row * ld + 16 * j + 4 * grp);
+      f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) f[s] = (row < nrows) ? src[(long long)row * ld + 4 * s + grp] : 0.f;
+  }
+}
+// the same fragment from an LDS tile (row stride DH + 4)
+template <int DH>
+__device__ __forceinline__ void lds_frag(float* f, const float* tile, int row, int grp) {
+  constexpr int LD = DH + 4;
+  if constexpr (DH % 16 == 0) {
+#pragma unroll
+    for (int j = 0; j < DH / 16; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(&tile[row * LD + 16 * j + 4 * grp]);
+      f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) f[s] = tile[row * LD + 4 * s + grp];
+  }
 }
 
 // S[tt] (tt = 0..NVT-1) = streamed rows 16tt..16tt+15 (from LDS) x own fragment.  NVT = 16-row tiles of
@@ -63,11 +90,28 @@ __device__ __forceinline__ void score_tiles(f32x4* S, const float* lds, const fl
   constexpr int LD = DH + 4;
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) S[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (DH % 16 == 0) {
 #pragma unroll
-  for (int s = 0; s < DH / 4; ++s) {
-    float b = frag[s];
+    for (int j = 0; j < DH / 16; ++j) {
+      float4 a[NVT];
 #pragma unroll
-    for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(lds[(16 * tt + c) * LD + 4 * s + grp], b, S[tt]);
+      for (int tt = 0; tt < NVT; ++tt) a[tt] = *reinterpret_cast<const float4*>(&lds[(16 * tt + c) * LD + 16 * j + 4 * grp]);
+#pragma unroll
+      for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(a[tt].x, frag[4 * j + 0], S[tt]);
+#pragma unroll
+      for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(a[tt].y, frag[4 * j + 1], S[tt]);
+#pragma unroll
+      for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(a[tt].z, frag[4 * j + 2], S[tt]);
+#pragma unroll
+      for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(a[tt].w, frag[4 * j + 3], S[tt]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < DH / 4; ++s) {
+      float b = frag[s];
+#pragma unroll
+      for (int tt = 0; tt < NVT; ++tt) S[tt] = mfma16(lds[(16 * tt + c) * LD + 4 * s + grp], b, S[tt]);
+    }
   }
 }
 
@@ -210,10 +254,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   load_frag<DH>(qf, Q, ld, qrow, N, grp);
   load_frag<DH>(dof, dOp, D, qrow, N, grp);
   float dl = 0.f;
+  {
+    float of_[DH / 4];
+    load_frag<DH>(of_, Op, D, qrow, N, grp);     // same k map as dof
 #pragma unroll
-  for (int s = 0; s < DH / 4; ++s) {
-    float ov = (qrow < N) ? Op[(long long)qrow * D + 4 * s + grp] : 0.f;
-    dl += dof[s] * ov;
+    for (int s = 0; s < DH / 4; ++s) dl += dof[s] * of_[s];
   }
   dl = grp_sum(dl);
   const float l2 = (qrow < N) ? lse2[((long long)img * N + qrow) * H + h] : 0.f;
@@ -348,7 +393,6 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
                                                              int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   AttnSmem4<DH>& sm = *reinterpret_cast<AttnSmem4<DH>*>(smem_raw);
-  constexpr int LD = DH + 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
   const int img = blockIdx.z, h = blockIdx.y;
   const int ld = 3 * D;
@@ -365,8 +409,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
   float* drow = dqkv + ((long long)img * N + row) * ld + h * DH;
   {  // ---- pass 1: own queries
     float qf[DH / 4], dof[DH / 4];
-#pragma unroll
-    for (int s = 0; s < DH / 4; ++s) { qf[s] = sm.sQ[row * LD + 4 * s + grp]; dof[s] = sm.sdO[row * LD + 4 * s + grp]; }
+    lds_frag<DH>(qf, sm.sQ, row, grp);
+    lds_frag<DH>(dof, sm.sdO, row, grp);
     f32x4 S[4], dP[4];
     score_tiles<DH>(S, sm.sK, qf, c, grp);
     score_tiles<DH>(dP, sm.sV, dof, c, grp);
@@ -402,8 +446,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
   __syncthreads();
   {  // ---- pass 2: own keys
     float kf[DH / 4], vf[DH / 4];
-#pragma unroll
-    for (int s = 0; s < DH / 4; ++s) { kf[s] = sm.sK[row * LD + 4 * s + grp]; vf[s] = sm.sV[row * LD + 4 * s + grp]; }
+    lds_frag<DH>(kf, sm.sK, row, grp);
+    lds_frag<DH>(vf, sm.sV, row, grp);
     f32x4 S[4], dP[4];
     score_tiles<DH>(S, sm.sQ, kf, c, grp);       // S[q][key]
     score_tiles<DH>(dP, sm.sdO, vf, c, grp);     // dP[q][key] = dO[q] . V[key]
