@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES) void gemm_kernel(GemmP p) {
 // Several independent TN problems (the weight-gradient contractions of one batch: different shapes,
 // each too small to fill the chip) in ONE launch: block -> (problem, tile) through a prefix table.
 template <int BF16>
-__global__ __launch_bounds__(256) void gemm_multi_tn_kernel(GemmMulti m) {
+__global__ __launch_bounds__(256, 5) void gemm_multi_tn_kernel(GemmMulti m) {
   int q = 0;
 #pragma unroll
   for (int k = 1; k < GEMM_MULTI_MAX; ++k) if (k < m.n && (int)blockIdx.x >= m.start[k]) q = k;
