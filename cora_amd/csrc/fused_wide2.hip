@@ -13,11 +13,17 @@
 //  * weight tiles are D/4 = 32 output rows x D inputs (16.9 KB), two LDS slots, 96 tiles per workgroup;
 //    stage k writes tile k+1 to LDS, fetches tile k+2 into the 4 staging float4 and multiplies with tile k,
 //    the three interleaved group by group;
-//  * K / V / Q / dO never sit in LDS whole: attention runs head by head on compact [64 tokens][32 + 4]
-//    tiles (4 x 9.2 KB) that each wave fills with its own rows' slice of the head; q, k, v (and P, and
-//    gelu'(a)) wait for the backward in an L2-resident stash instead of LDS / registers;
+//  * K / V / Q / dO never sit in LDS whole: attention runs head by head on compact head tiles that each
+//    wave fills with its own rows' slice of the head -- [64 tokens][32 + 4] for the operands of the
+//    score-shaped products (contraction over the head dim), transposed [32][64 + 4] for the operands of
+//    the products that sum over tokens (one ds_read_b128 per four MFMAs); four 9.2 KB slots in the
+//    forward (K, V^T of two heads), six tiles in the backward (V, Q, dO and K^T, Q^T, dO^T of one head:
+//    the four slots plus the weight slot that idles there); q, k, v (and P, and gelu'(a)) wait for the
+//    backward in an L2-resident stash instead of LDS / registers;
 //  * 76.8 KB of LDS per workgroup: 2 weight slots 33.8 KB, 4 head tiles 36.9 KB, LSE / delta rows 2 KB,
 //    parameter block (b1, LN2 gamma / beta, b2, LN1 gamma) 4 KB.
+// The same file holds the chain kernel (status "forward": INIT pass and reconstruction), the forward half
+// of the block body walking one image through all L blocks.
 #include "common.h"
 
 #include "fused_wide_common.h"
@@ -42,27 +48,6 @@ __device__ __forceinline__ void gemm_hd(const float* __restrict__ t, const float
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].w, xs[4 * c + 3], acc[ot]);
   }
-}
-// out[4 c + reg'] = scale * sum over the 64 tile rows j of T[j][16 c + 4 grp + reg'] * pf[j]
-template <int LDH, int NCH>
-__device__ __forceinline__ void accum_hd(const float* __restrict__ t, const float* pf, float* out, float scale, int i, int grp) {
-  f32x4 acc[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const lds_float* tl = opaque(t + 4 * grp * LDH + i);
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const lds_float* row = &tl[(16 * tt + reg) * LDH];
-      const float b = pf[4 * tt + reg];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = mfma16(row[16 * c], b, acc[c]);
-    }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[4 * c + reg] = acc[c][reg] * scale;
 }
 // this wave's rows of a head slice (NCH column groups, 4 NCH registers) -> its rows of a head tile
 template <int LDH, int NCH>
