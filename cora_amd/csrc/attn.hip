@@ -30,6 +30,16 @@ struct AttnSmem {
   float s2[CH * LD];
   float rowc[2 * CH];  // per streamed row constants (lse2, delta) for bwd-kv
 };
+// forward and bwd-q carry no row constants: at head dim 48 the 512 bytes decide between five and six
+// workgroups per CU (6 x 26 624 B = 159 744 B of the 160 KB).  The kernels' launch bounds ask for 6 / 5 / 4
+// waves per SIMD (forward / bwd-q / bwd-kv) at head dims <= 48, where that costs no spills; these kernels
+// hide their staging latency with co-resident workgroups, not inside one
+template <int DH>
+struct AttnSmem2 {
+  static constexpr int LD = DH + 4;
+  float s1[CH * LD];
+  float s2[CH * LD];
+};
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -153,10 +163,10 @@ __device__ __forceinline__ float grp_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
+__global__ __launch_bounds__(256, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
                                                        float* __restrict__ lse2, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
+  AttnSmem2<DH>& sm = *reinterpret_cast<AttnSmem2<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
   const int img = blockIdx.z, h = blockIdx.y;
   const int ld = 3 * D;
@@ -231,12 +241,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+__global__ __launch_bounds__(256, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
                                                          const float* __restrict__ lse2, const float* __restrict__ dO,
                                                          float* __restrict__ delta, float* __restrict__ dqkv,
                                                          int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
+  AttnSmem2<DH>& sm = *reinterpret_cast<AttnSmem2<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
   const int img = blockIdx.z, h = blockIdx.y;
   const int ld = 3 * D;
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+__global__ __launch_bounds__(256, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
                                                           const float* __restrict__ dO, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 template <int DH>
 static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
-  size_t sm = sizeof(AttnSmem<DH>);
+  size_t sm = sizeof(AttnSmem2<DH>);
   static bool attr_set[64] = {};
   if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -508,7 +518,7 @@ static int run_bwd(const float* qkv, const float* O, const float* lse2, const fl
     (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   }
   dim3 grid((N + 63) / 64, H, nimg);
-  hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, dO, delta, dqkv, N, H, D);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, dim3(256), sizeof(AttnSmem2<DH>), st, qkv, O, lse2, dO, delta, dqkv, N, H, D);
   hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, dim3(256), sm, st, qkv, lse2, dO, delta, dqkv, N, H, D);
   return 0;
 }
