@@ -265,11 +265,14 @@ def test_vode_state_layernorm(name):
     assert any("vode_output_layernorms" in k for k in errs)
 
 
-@pytest.mark.parametrize("vode_ln", [False, True])
-def test_init_forward_energy_api(vode_ln):
-    """INIT forward (h_l := u_l chained), status-None energy() and status-"forward" reconstruction."""
+@pytest.mark.parametrize("name,vode_ln", [("tiny_2block_h2", False), ("tiny_2block_h2", True),
+                                          ("cfg2_shape_B4", False), ("cfg3_shape_B2", False), ("d96_h2", False)])
+def test_init_forward_energy_api(name, vode_ln):
+    """INIT forward (h_l := u_l chained), status-None energy() and status-"forward" reconstruction -- on the
+    per-op chain, the D=64 chain kernel (cfg 2 shape), the wide chain kernel (cfg 3 shape: one workgroup walks
+    one image through 12 blocks) and the per-op chain under the one-workgroup wide kernel (D=96)."""
     import cora_amd as ca
-    shape, p, D, H, L, B, T = CASES["tiny_2block_h2"]
+    shape, p, D, H, L, B, T = CASES[name]
     case = make_case(shape, p, D, H, L, B, seed=11, vode_ln=vode_ln)
     model, _, _ = build_model(case)
     model.init_vodes(B, h0=case["h0"])
