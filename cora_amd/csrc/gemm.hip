@@ -19,6 +19,9 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+#ifndef GEMM_EP_STREAM
+#define GEMM_EP_STREAM false   /* streamed C was measured on the fp32 kernel too: -1.5 % on the cfg 4 GEMMs, within noise on the step */
+#endif
 #define BM 128
 #define BN 64
 
@@ -208,7 +211,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const in
   const GemmEp q = gemm_ep_ptrs(p, g);
   double red = 0.0;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) gemm_ep_tile(p, q, acc[n], row0 + 32 * w + 4 * hi, col0 + 32 * n + r, red);
+  for (int n = 0; n < 2; ++n) gemm_ep_tile<GEMM_EP_STREAM>(p, q, acc[n], row0 + 32 * w + 4 * hi, col0 + 32 * n + r, red);
   gemm_ep_reduce(p, g, bx, red, red_sh);
 }
 
