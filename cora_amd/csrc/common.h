@@ -118,6 +118,9 @@ struct GemmP {
   const float* aux;      // OUT_GELUGRAD: pre-activation a   (ld = ldc)
   float alpha2, l1, l2;
   double* red; int red_stride;   // red[g * red_stride] accumulates energy / sum of squares
+  // bf16 mode: the B operand (a weight) already converted to bf16, hi (and lo for the split form), indexed
+  // like Bw (ctx.hip keeps the copies fresh); null -> B is converted from Bw while staging
+  const unsigned short* Bh; const unsigned short* Bl;
 };
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
@@ -196,6 +199,8 @@ void launch_adamw(const AdamP& p, hipStream_t st);
 // red[0] += sum (clip01(a)-clip01(b))^2
 void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st);
 void launch_zero(void* ptr, size_t bytes, hipStream_t st);
+// bf16 copies of n floats: hi = bf16(x), lo = bf16(x - hi) (lo may be null)
+void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st);
 
 // ---- fused per-(block, image) kernel (N = 64, D = 64, H = 1) -----------------------------------------
 struct FusedP {

@@ -109,6 +109,9 @@ struct cora_ctx {
   float* pos = nullptr;
   float* WT = nullptr;      // transposed copies for the fused kernel's backward GEMMs
   size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, tWp = 0, tWout = 0, nWT = 0;
+  // bf16 mode: bf16 copies of the weights (hi, lo: forward GEMMs use the split form) and of their transposes
+  // (hi only: backward-data GEMMs use plain bf16), refreshed with WT after every weight update
+  unsigned short *Wh = nullptr, *Wl = nullptr, *WTh = nullptr;
   bool fused = false;     // D = 64 fused kernel (inference, STORE and chain modes)
   bool fusedw = false;    // D = 96 / 128 fused kernel (inference step only; learning phase and chain stay per-op)
   bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
@@ -260,7 +263,14 @@ GemmP gemm_base(cora_ctx* c, int kind = 0 /* 0 forward, 1 backward-data, 2 weigh
   return p;
 }
 
-void run_gemm(cora_ctx* c, const GemmP& p, bool ako, bool bko) {
+void run_gemm(cora_ctx* c, const GemmP& p_in, bool ako, bool bko) {
+  GemmP p = p_in;
+  static const bool no_pre = getenv("CORA_BF16_NO_PRE") != nullptr;   // diagnostic: convert weights while staging
+  if (c->Wh && p.bf16 && !ako && !bko && !no_pre) {
+    // bf16 mode, weight operand: hand the kernel the copy that is already bf16 (same element offsets)
+    if (p.Bw >= c->W && p.Bw < c->W + c->nW) { p.Bh = c->Wh + (p.Bw - c->W); p.Bl = c->Wl + (p.Bw - c->W); }
+    else if (p.bf16 == 1 && c->WT && p.Bw >= c->WT && p.Bw < c->WT + c->nWT) { p.Bh = c->WTh + (p.Bw - c->WT); p.Bl = nullptr; }
+  }
   int kind = ako ? K_GEMM_TN : (bko ? K_GEMM_NN : K_GEMM_NT);
   double fl = 2.0 * p.R * (double)p.O * p.K * p.groups;
   double by = 4.0 * p.groups * ((double)p.R * p.K + (double)p.O * p.K + (double)p.R * p.O);
@@ -421,6 +431,10 @@ void refresh_wt(cora_ctx* c) {
   add(c->oWqkv, c->tWqkv, 3 * D, D, L); add(c->oWo, c->tWo, D, D, L); add(c->oW1, c->tW1, M, D, L);
   add(c->oW2, c->tW2, D, M, L); add(c->oWp, c->tWp, D, c->P, 1); add(c->oWout, c->tWout, c->P, D, 1);
   launch_transpose_set(t, c->st);
+  if (c->Wh) {
+    launch_cvt_bf16(c->W, c->Wh, c->Wl, (long long)c->nW, c->st);
+    launch_cvt_bf16(c->WT, c->WTh, nullptr, (long long)c->nWT, c->st);
+  }
 }
 
 // flops of one block forward + VJP per image (2 FLOP per MAC): 48 N D^2 + 12 N^2 D
@@ -786,6 +800,12 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
     c->nWT = t;
     DA(c->WT, c->nWT);
+    if (cfg->dtype_mode == 1) {
+      float* tmpb = nullptr;
+      DA(tmpb, (long long)(c->nW + 1) / 2 + 4); c->Wh = (unsigned short*)tmpb;
+      DA(tmpb, (long long)(c->nW + 1) / 2 + 4); c->Wl = (unsigned short*)tmpb;
+      DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WTh = (unsigned short*)tmpb;
+    }
     if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);

@@ -67,7 +67,7 @@ __device__ __forceinline__ bf16x4 to_bf16_lo(const float4 v, const bf16x4 h) {
 #ifndef BF_OCC
 #define BF_OCC 2
 #endif
-template <int SPLIT>
+template <int SPLIT, bool BPRE>
 __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
   __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
 
   // staging: float4 #f of a 128 x TK tile = row f / KQ, k quad f % KQ; thread t takes #t + 256 i (row t / KQ + RSTEP i)
   const int srow = tid / KQ, skq = tid % KQ;
-  float4 ra[NV], rb[NV];
+  float4 ra[NV], rb[BPRE ? 1 : NV];
+  uint4 pbh[2], pbl[2];
   auto load_tiles = [&](int k0) {
     const int gk = k0 + 4 * skq;
     const bool kok = gk < p.K;
@@ -99,10 +100,25 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       const int gr = row0 + srow + RSTEP * i;
       ra[i] = (kok && gr < p.R) ? *reinterpret_cast<const float4*>(A + (long long)gr * p.lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (BPRE) {
+      // weights converted once per weight update (ctx.hip: refresh_wt): 16-byte pieces of 8 bf16 go to LDS as
+      // they are -- piece #f of the 128 x 32 tile = row f / 4, k octet f % 4; thread t takes #t and #t + 256
+      static_assert(!BPRE || (NTHR == 256 && TK == 32), "pre-converted B staging is written for 256 threads, 32-deep slabs");
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int gc = col0 + srow + RSTEP * i;
-      rb[i] = (kok && gc < p.O) ? *reinterpret_cast<const float4*>(Bw + (long long)gc * p.ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const int gc = col0 + (f >> 2), gkb = k0 + 8 * (f & 3);
+        const bool ok = gkb < p.K && gc < p.O;
+        const long long off = (long long)g * p.sB + (long long)gc * p.ldb + gkb;
+        pbh[i] = ok ? *reinterpret_cast<const uint4*>(p.Bh + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (SPLIT) pbl[i] = ok ? *reinterpret_cast<const uint4*>(p.Bl + off) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int gc = col0 + srow + RSTEP * i;
+        rb[i] = (kok && gc < p.O) ? *reinterpret_cast<const float4*>(Bw + (long long)gc * p.ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto store_tiles = [&]() {
@@ -115,13 +131,23 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       *reinterpret_cast<bf16x4*>(&Ah[o]) = h;
       if (SPLIT) *reinterpret_cast<bf16x4*>(&Al[o]) = to_bf16_lo(v, h);
     }
+    if (BPRE) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float4 v = rb[i];
-      const int o = (srow + RSTEP * i) * LDR + 4 * skq;
-      const bf16x4 h = to_bf16(v);
-      *reinterpret_cast<bf16x4*>(&Bh[o]) = h;
-      if (SPLIT) *reinterpret_cast<bf16x4*>(&Bl[o]) = to_bf16_lo(v, h);
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const int o = (f >> 2) * LDR + 8 * (f & 3);
+        *reinterpret_cast<uint4*>(&Bh[o]) = pbh[i];
+        if (SPLIT) *reinterpret_cast<uint4*>(&Bl[o]) = pbl[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 v = rb[i];
+        const int o = (srow + RSTEP * i) * LDR + 4 * skq;
+        const bf16x4 h = to_bf16(v);
+        *reinterpret_cast<bf16x4*>(&Bh[o]) = h;
+        if (SPLIT) *reinterpret_cast<bf16x4*>(&Bl[o]) = to_bf16_lo(v, h);
+      }
     }
   };
 
@@ -205,6 +231,14 @@ void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st) {
   const int tx = (p.R + TM - 1) / TM, ty = (p.O + TN - 1) / TN;
   const int ntiles = tx * ty * p.groups;
   const dim3 grid(((ntiles + 7) / 8) * 8);
-  if (p.bf16 == 2) hipLaunchKernelGGL((gemm_bf16_nt_kernel<1>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
-  else hipLaunchKernelGGL((gemm_bf16_nt_kernel<0>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+  // pre-converted weights need 16-byte aligned octets of k
+  const bool pre = p.Bh != nullptr && (p.bf16 != 2 || p.Bl != nullptr) && p.K % 8 == 0 && p.ldb % 8 == 0 && p.sB % 8 == 0 &&
+                   ((uintptr_t)p.Bh % 16) == 0 && (p.bf16 != 2 || ((uintptr_t)p.Bl % 16) == 0);
+  if (p.bf16 == 2) {
+    if (pre) hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, false>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+  } else {
+    if (pre) hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, false>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+  }
 }

@@ -510,3 +510,25 @@ void launch_zero(void* ptr, size_t bytes, hipStream_t st) {   // bytes % 16 == 0
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4*)ptr, n4);
 }
+
+// ---- bf16 copies of a weight arena (bf16 mode, gemm_bf16.hip) ---------------------------------------
+// hi = bf16(x) (round to nearest even), lo = bf16(x - hi): the same two conversions the GEMM kernel applies
+// to an operand it converts itself while staging, so both forms give bit-identical products.
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi,
+                                                       unsigned short* __restrict__ lo, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float x = src[i];
+    const __bf16 h = (__bf16)x;
+    hi[i] = __builtin_bit_cast(unsigned short, h);
+    if (lo) {
+      const __bf16 l = (__bf16)(x - (float)h);
+      lo[i] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
+}
+void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, hi, lo, n);
+}
