@@ -238,3 +238,26 @@ def test_optim_init_resets_schedule_count():
     ow.count = 7
     ow.init()
     assert ow.count == 0 and ow._recipe().base.weight_decay == 1e-4
+
+
+def test_round2_entry_points_reject_bad_arguments_without_a_gpu():
+    """Error behaviour of the entry points added in round 2 (no compute, no GPU): null contexts and malformed
+    buffers come back as negative status codes with a message, never as a crash."""
+    import ctypes as C
+    lib = _lib.load()
+    out = _lib.CoraStepOut()
+    assert lib.cora_step_dist(None, None, 0, 20, None, C.c_float(1e-3), 1, C.byref(out)) == -1
+    assert lib.cora_comm_init(None, None, 128, 0, 1) == -1
+    assert lib.cora_comm_info(None, None, None) == -1
+    assert lib.cora_kernel_path(None) == -1
+    small = C.create_string_buffer(16)
+    assert lib.cora_comm_unique_id(small, 16) == -1           # the RCCL id is 128 bytes
+    assert b"128" in lib.cora_last_error(None)
+    # allocation-free forward: nulls and oversize problems are refused before anything touches a device
+    cfg = _lib.CoraConfig(N=64, P=48, D=64, H=1, M=256, L=6, B=200, C=3, patch=4, Himg=32, Wimg=32, F=1, dtype_mode=0,
+                          max_T=64)
+    assert lib.cora_forward_static(C.byref(cfg), 0, None, 0, None, None, None, None) == -1
+    assert lib.cora_forward_static_floats(C.byref(cfg)) > 4 * 1024 * 1024      # B=200 does not fit the 16 MiB array
+    dummy = C.create_string_buffer(64)
+    rc = lib.cora_forward_static(C.byref(cfg), 0, dummy, 1, dummy, dummy, dummy, None)
+    assert rc != 0 and (b"scratch" in lib.cora_last_error(None) or b"weight" in lib.cora_last_error(None))
