@@ -175,30 +175,36 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
     tc = ca.transformer_config_from(mc)
     T = T or mc.inference_steps
     lib = _lib.load()
-    model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=args.dtype)
     rng = np.random.default_rng(1234 + rank)
     x_host = rng.uniform(0, 1, (B,) + tuple(tc.image_shape)).astype(np.float32)
-    h0 = (0.01 * rng.standard_normal((B, model.N, model.P))).astype(np.float32)
-    model.init_vodes(B, h0=h0)
-    optim_w, optim_h = ca.make_optimizers(mc, model, total_train_steps=steps + warmup)
-    model._apply_recipes(optim_w, optim_h)
-    ctx = model._ctx
-    dp, mode = None, "single"
     force_dp = os.environ.get("CORA_FORCE_DP") == "1"     # exercise the N>1 code path on one GPU
-    if world > 1 or force_dp:
-        from cora_amd.dist import DataParallel
-        exact = args.clip_mode == "exact"
-        backend = args.dp_backend
-        if backend == "rccl":
-            try:
-                dp = DataParallel(model, B, exact_clip=exact, backend="rccl")
-            except Exception as e:       # RCCL could not be bound inside the library: say so, use the split step
-                print(f"[bench] in-library RCCL unavailable ({e}); falling back to the torch.distributed path", file=sys.stderr)
-                backend = "torch"
-        if backend == "torch":
-            exact = False                # the split step's exact mode is a host round trip per inference step
-            dp = DataParallel(model, B, exact_clip=False, backend="torch")
-        mode = f"{backend}:{'exact' if exact else 'local'}-clip"
+
+    def build(backend):
+        """Model + data-parallel binding.  backend: None (one GPU), "rccl" (collectives inside the library's
+        graphs) or "torch" (step split at the exchange point, per-shard clip)."""
+        model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=args.dtype)
+        h0 = (0.01 * np.random.default_rng(4321 + rank).standard_normal((B, model.N, model.P))).astype(np.float32)
+        model.init_vodes(B, h0=h0)
+        optim_w, optim_h = ca.make_optimizers(mc, model, total_train_steps=steps + warmup)
+        model._apply_recipes(optim_w, optim_h)
+        dp, mode = None, "single"
+        if backend is not None:
+            from cora_amd.dist import DataParallel
+            exact = args.clip_mode == "exact"
+            if backend == "rccl":
+                try:
+                    dp = DataParallel(model, B, exact_clip=exact, backend="rccl")
+                except Exception as e:       # RCCL could not be bound inside the library: say so, use the split step
+                    print(f"[bench] in-library RCCL unavailable ({e}); falling back to the torch.distributed path", file=sys.stderr)
+                    backend = "torch"
+            if backend == "torch":
+                exact = False                # the split step's exact mode is a host round trip per inference step
+                dp = DataParallel(model, B, exact_clip=False, backend="torch")
+            mode = f"{backend}:{'exact' if exact else 'local'}-clip"
+        return model, dp, mode
+
+    model, dp, mode = build(args.dp_backend if (world > 1 or force_dp) else None)
+    ctx = model._ctx
     x_dev = torch.from_numpy(x_host).cuda()
     torch.cuda.synchronize()
     eta_h = np.full(T, mc.peak_lr_hidden, dtype=np.float32)
@@ -223,8 +229,28 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        one_step()
+    # warm-up; if the in-library RCCL step fails on any rank (e.g. a collective the runtime will not run under a
+    # graph), every rank rebuilds on the torch.distributed path instead of losing the run
+    failed = 0
+    try:
+        for _ in range(warmup):
+            one_step()
+    except _lib.CoraError as e:
+        if dp is None or not dp.in_library:
+            raise
+        failed = 1
+        print(f"[bench] rank {rank}: in-library RCCL step failed ({e})", file=sys.stderr)
+    if dist is not None and dp is not None and dp.in_library:
+        flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = int(flag.item())
+    if failed:
+        print("[bench] falling back to the torch.distributed data-parallel path (per-shard clip)", file=sys.stderr)
+        model.close()
+        model, dp, mode = build("torch")
+        ctx = model._ctx
+        for _ in range(warmup):
+            one_step()
     barrier()
     t0 = time.perf_counter()
     infer_ms = 0.0
