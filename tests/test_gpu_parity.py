@@ -116,7 +116,7 @@ def test_regularisers_and_clipping():
 BF16_TOL = 1e-2
 
 
-@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1"])
+@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk"])
 def test_bf16_opt_in(name):
     """Opt-in bf16 mode (BASELINE.json north_star: "bf16 as an opt-in mode", bar rel <= 1e-2 on final
     vodes, per-step energies and weight gradients; configs[3] names bf16 MFMA for the 224x224 case):
