@@ -16,7 +16,7 @@ def main():
     from tests.parity_cases import FULL_CASES, TOL, run_full_case, summarise
     from tests import test_gpu_parity as small
     table = {"bar_rule": "plain 1e-4 on vodes (h*), energies, weight gradients (gw*), final_w_energy, train_mse; "
-                         "max(1e-4, 3 x fp32-oracle floor) on final_h_grad (gh*) only; 1e-5 on the AdamW kernel check; "
+                         "max(1e-4, 3 x fp32-oracle floor) on final_h_grad (gh*) only; 1e-5 on the AdamW kernel check; bf16/* cases: 1e-2; "
                          "err and floor are max-abs / max-abs per tensor (weight gradients: over all weight gradients)",
              "cases": {}}
     for name in FULL_CASES:
@@ -33,6 +33,13 @@ def main():
         table["cases"]["small/" + name] = {"info": {"shape": list(map(str, shape))}, "worst": {worst: rows[worst]},
                                            "n_tensors": len(rows), "above_1e-4_bar": sorted(relaxed), "rows": rows}
         print("small/" + name, "worst", worst, rows[worst], "relaxed", len(relaxed), flush=True)
+    for name in small.BF16_CASES:
+        errs = small.run_bf16_case(name)
+        rows = {k: {"err": v, "floor": None, "bar": small.BF16_TOL} for k, v in errs.items()}
+        worst = max(errs, key=errs.get)
+        table["cases"]["bf16/" + name] = {"info": {"shape": list(map(str, small.CASES[name])), "mode": "dtype_mode = 1 (bf16 MFMA operands)"},
+                                          "worst": {worst: rows[worst]}, "n_tensors": len(rows), "above_1e-4_bar": [], "rows": rows}
+        print("bf16/" + name, "worst", worst, rows[worst], flush=True)
     with open(out, "w") as f:
         json.dump(table, f, indent=1)
     print("wrote", out)

@@ -116,13 +116,11 @@ def test_regularisers_and_clipping():
 BF16_TOL = 1e-2
 
 
-@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk"])
-def test_bf16_opt_in(name):
-    """Opt-in bf16 mode (BASELINE.json north_star: "bf16 as an opt-in mode", bar rel <= 1e-2 on final
-    vodes, per-step energies and weight gradients; configs[3] names bf16 MFMA for the 224x224 case):
-    GEMM operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16, accumulation and
-    every stored tensor stay fp32.  Gradients are compared per tensor against the largest entry of
-    that tensor family, as in the fp32 test."""
+BF16_CASES = ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk"]
+
+
+def run_bf16_case(name):
+    """One train_on_batch step in bf16 mode against the fp64 oracle: {tensor: max|a-b| / max|b|}."""
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
     case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000)
@@ -139,6 +137,17 @@ def test_bf16_opt_in(name):
     for k, v in ref["w_grad"].items():
         errs["gw" + k] = float(np.abs(gw[k].astype(np.float64) - v).max() / gnorm)
     model.close()
+    return errs
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_bf16_opt_in(name):
+    """Opt-in bf16 mode (BASELINE.json north_star: "bf16 as an opt-in mode", bar rel <= 1e-2 on final
+    vodes, per-step energies and weight gradients; configs[3] names bf16 MFMA for the 224x224 case):
+    GEMM operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (two-term split for the
+    forward predictions), accumulation and every stored tensor stay fp32.  Gradients are compared per
+    tensor against the largest entry of that tensor family, as in the fp32 test."""
+    errs = run_bf16_case(name)
     print(name, "bf16 max rel err", max(errs.values()), max(errs, key=errs.get))
     bad = {k: v for k, v in errs.items() if not v <= BF16_TOL}
     assert not bad, f"{name}: bf16 parity failures: {bad}"
