@@ -186,9 +186,10 @@ struct VodeGradP {
 };
 void launch_vode_grad(const VodeGradP& p, hipStream_t st);
 // column sums: out[g*sOut + c] += alpha * sum_rows a[row, c] * (b ? b'[row, c] : 1), where
-// b' = b, or (b - mean[row]) * rstd[row] when stats ([rows,2]) is given
+// b' = b, or (b - mean[row]) * rstd[row] when stats ([rows,2]) is given; out2 (optional): the plain column
+// sums of a from the same pass.  cols % 4 == 0.
 void launch_colsum(const float* a, const float* b, const float* stats, float* out, long long sOut,
-                   int rows_per_group, int groups, int cols, float alpha, hipStream_t st);
+                   int rows_per_group, int groups, int cols, float alpha, hipStream_t st, float* out2 = nullptr);
 void launch_sumsq(const float* a, long long n, float scale, double* out, hipStream_t st);
 struct AdamP {
   float* w; const float* g; float* mu; float* nu; long long n;

@@ -1183,10 +1183,8 @@ int enqueue_wgrad(cora_ctx* c) {
       KScope s(c, K_OTHER, 0, 4.0 * L * R * (6.0 * D + M));
       launch_colsum(r, nullptr, nullptr, c->dW + c->ob2, D, R, L, D, -1.f, c->st);
       launch_colsum(c->da, nullptr, nullptr, c->dW + c->ob1, M, R, L, M, -1.f, c->st);
-      launch_colsum(c->dzn, c->y, c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st);
-      launch_colsum(c->dzn, nullptr, nullptr, c->dW + c->oLn2b, D, R, L, D, -1.f, c->st);
-      launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st);
-      launch_colsum(c->dxn, nullptr, nullptr, c->dW + c->oLn1b, D, R, L, D, -1.f, c->st);
+      launch_colsum(c->dzn, c->y, c->st2, c->dW + c->oLn2g, D, R, L, D, -1.f, c->st, c->dW + c->oLn2b);   // d gamma and d beta in one pass
+      launch_colsum(c->dxn, xin, c->st1, c->dW + c->oLn1g, D, R, L, D, -1.f, c->st, c->dW + c->oLn1b);
     }
   }
   if (c->vln) {   // vode LayerNorm parameters: d gamma_v = -sum dx'_v * xhat_v, d beta_v = -sum dx'_v
@@ -1195,8 +1193,7 @@ int enqueue_wgrad(cora_ctx* c) {
     p.R = R; p.O = D; p.K = P; p.lda = P; p.ldc = D; p.mode = OUT_STORE;
     run_gemm(c, p, false, bwd_weight(c, p, c->oWout, c->tWout));  // dx'_{L+1} = e_img Wout
     KScope s(c, K_OTHER, 0, 12.0 * (L + 1) * R * D);
-    launch_colsum(c->dxr, vode_ptr(c, c->Hs, 1), c->stv, c->dW + c->oVg, D, R, L + 1, D, -1.f, c->st);
-    launch_colsum(c->dxr, nullptr, nullptr, c->dW + c->oVb, D, R, L + 1, D, -1.f, c->st);
+    launch_colsum(c->dxr, vode_ptr(c, c->Hs, 1), c->stv, c->dW + c->oVg, D, R, L + 1, D, -1.f, c->st, c->dW + c->oVb);
   }
   return 0;
 }
