@@ -685,9 +685,15 @@ int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
 
 int upload_x(cora_ctx* c, const float* x, int on_device) {
   if (!x) FAIL(-1, "x is NULL");
-  HCHECK(hipMemcpyAsync(c->ximg, x, sizeof(float) * (size_t)c->nImg, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
+  // host x is staged through ximg; device x is patchified where it lies (every caller of upload_x ends its
+  // entry point with a stream synchronisation or documents that x must stay valid until the step is settled)
+  const float* src = x;
+  if (!on_device) {
+    HCHECK(hipMemcpyAsync(c->ximg, x, sizeof(float) * (size_t)c->nImg, hipMemcpyHostToDevice, c->st));
+    src = c->ximg;
+  }
   KScope s(c, K_OTHER, 0, 8.0 * c->nImg);
-  launch_patchify(c->ximg, c->xp, c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 0, c->st);
+  launch_patchify(src, c->xp, c->B, c->cfg.F, c->cfg.C, c->cfg.Himg, c->cfg.Wimg, c->cfg.patch, 0, c->st);
   return 0;
 }
 
@@ -1235,6 +1241,21 @@ int stage_adam_hyp(cora_ctx* c, float eta_w) {
   return 0;
 }
 
+// Step scalars to the pinned host buffer: [energy row of step T-1 (8 slots per vode, or plain)] [w-energy row]
+// [mse sum].  (A gather kernel writing through the device view of the pinned buffer instead of the three
+// copies was measured: no difference, 835-842 k either way at cfg 2.)
+static int enqueue_result_readback(cora_ctx* c, int T) {
+  const int L = c->L;
+  double* ho = c->host_out;
+  const size_t nslot = (size_t)(L + 3) * 8;
+  const double* erow = c->slotted() ? c->esum + (long long)(T - 1) * (L + 3) * 8 : c->energies + (long long)(T - 1) * (L + 3);
+  const size_t nrow = c->slotted() ? nslot : (size_t)(L + 3);
+  HCHECK(hipMemcpyAsync(ho, erow, sizeof(double) * nrow, hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
+  HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  return 0;
+}
+
 int cora_wgrad(cora_ctx* c, cora_step_out* out) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
@@ -1406,10 +1427,7 @@ int cora_step(cora_ctx* c, const float* x, int x_on_device, int T, const float* 
   // scalars back through pinned memory: [energy row of step T-1 (slots or plain)] [w-energy row] [mse sum]
   double* ho = c->host_out;
   const size_t nslot = (size_t)(L + 3) * 8;
-  if (c->slotted()) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
-  else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
-  HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
-  HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  if (int rcr = enqueue_result_readback(c, T)) return rcr;
   HCHECK(hipStreamSynchronize(c->st));
   if (out) {
     float ms = 0.f;
@@ -1681,10 +1699,7 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
   HCHECK(hipEventRecord(c->ev2, c->st));
   double* ho = c->host_out;
   const size_t nslot = (size_t)(L + 3) * 8;
-  if (c->slotted()) HCHECK(hipMemcpyAsync(ho, c->esum + (long long)(T - 1) * (L + 3) * 8, sizeof(double) * nslot, hipMemcpyDeviceToHost, c->st));
-  else HCHECK(hipMemcpyAsync(ho, c->energies + (long long)(T - 1) * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
-  HCHECK(hipMemcpyAsync(ho + nslot, c->energies + (long long)c->Tmax * (L + 3), sizeof(double) * (L + 3), hipMemcpyDeviceToHost, c->st));
-  HCHECK(hipMemcpyAsync(ho + nslot + (L + 3), c->scal + 1, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  if (int rcr = enqueue_result_readback(c, T)) return rcr;
   HCHECK(hipStreamSynchronize(c->st));
   c->dist_warm = true;
   c->learn_warm = true;
