@@ -11,7 +11,10 @@
 // Both operands are K-inner ("NT"): activations [row][k] and weights [out][in].  The backward-data
 // GEMMs, whose weight is K-outer as stored, read the transposed weight copies the context keeps in
 // bf16 mode (ctx.hip: refresh_wt), so one operand form serves every GEMM of the inference step; the
-// weight-gradient contractions (K-outer on both sides, once per batch) stay on gemm.hip.
+// weight-gradient contractions (K-outer on both sides, once per batch) stay on gemm.hip.  BPRE: the weight
+// operand comes from bf16 copies the context refreshes with every weight update (hi, and lo for the split
+// form) and goes to LDS as 16-byte pieces without conversion -- bit-identical products, -8 % on the cfg 4
+// GEMM set.
 //
 // Tile 128 x 128 x 32, 256 threads = 2 x 2 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator
 // registers): per 16-deep k step a wave reads 2 + 2 fragments for 4 MFMAs (split: 4 + 4 for 12).
