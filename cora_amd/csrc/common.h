@@ -237,6 +237,8 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st);
 // status-"forward" walk of one image per workgroup through all L blocks (D = 128, heads of 32); in place when
 // stride == 0 and xin == xout, else block g's output goes to xout + g * stride
 int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st);
+// the same for every shape fused_wide_supported() takes (one workgroup per CU form)
+int launch_chain_wide(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st);
 void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
 size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

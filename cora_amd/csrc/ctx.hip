@@ -659,15 +659,17 @@ int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
   float* cur = into_vodes ? vode_ptr(c, c->Hs, 1) : c->ua;
   patch_proj(c, vode_ptr(c, c->Hs, 0), cur, OUT_STORE, nullptr, nullptr);
   static const bool no_chain = getenv("CORA_NO_WIDE_CHAIN") != nullptr;   // diagnostic: per-op chain on the wide path
-  if (c->fusedw2 && L > 0 && !no_chain) {
-    // one workgroup walks one image through all L blocks (fused_wide2.hip: wide2_chain_body); INIT keeps every
-    // u as the next vode, the reconstruction walks in place
+  if (c->fusedw && L > 0 && !no_chain) {
+    // one workgroup walks one image through all L blocks (fused_wide2.hip: wide2_chain_body, fused_wide.hip:
+    // wide_chain_body); INIT keeps every u as the next vode, the reconstruction walks in place
     FusedP f;
     fill_fused(c, f, nullptr, nullptr);
     double fl = (double)c->B * L * (24.0 * c->N * c->D * (double)c->D + 4.0 * c->N * (double)c->N * c->D);
     {
       KScope s(c, K_OTHER, fl, 0);
-      if (launch_chain_wide2(f, L, cur, into_vodes ? vode_ptr(c, c->Hs, 2) : cur, into_vodes ? c->nl : 0, c->st))
+      float* xo = into_vodes ? vode_ptr(c, c->Hs, 2) : cur;
+      const long long stride = into_vodes ? c->nl : 0;
+      if (c->fusedw2 ? launch_chain_wide2(f, L, cur, xo, stride, c->st) : launch_chain_wide(f, L, c->D, cur, xo, stride, c->st))
         FAIL(-3, "wide chain kernel launch failed");
     }
     out_proj(c, into_vodes ? vode_ptr(c, c->Hs, L + 1) : cur, c->z, OUT_STORE, nullptr, nullptr);

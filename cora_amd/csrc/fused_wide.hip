@@ -61,6 +61,72 @@
 #define SSTAMP(J) do {} while (0)
 #endif
 
+// ---- weight tile pipeline macros (shared by the block body and the chain body) ----------------------------
+// They name locals both bodies define: tile_src, the staging registers sr0..sr7, tid / i / grp, wbuf, slot,
+// NT (tiles the workgroup walks through), HOLD (a stage that neither publishes nor prefetches, or -1) and the
+// WideCfg constants.
+#define PF_ONE(J, REG, SRC, LDW)                                                                  \
+  if constexpr (NST > (J)) {                                                                      \
+    const int f_ = tid + 256 * (J);                                                               \
+    if (NF4 % 256 == 0 || f_ < NF4)                                                               \
+      REG = *reinterpret_cast<const float4*>((SRC) + (long long)(f_ / (D / 4)) * (LDW) + 4 * (f_ % (D / 4))); \
+  }
+#define PB_ONE(J, REG, WB)                                                                        \
+  if constexpr (NST > (J)) {                                                                      \
+    const int f_ = tid + 256 * (J);                                                               \
+    if (NF4 % 256 == 0 || f_ < NF4)                                                               \
+      lds_st4((WB) + (f_ / (D / 4)) * LD + 4 * (f_ % (D / 4)), REG);                              \
+  }
+  // whole-tile forms (prologue, and the restart after the attention backward)
+#define PREFETCH_ALL(K)                                                                           \
+  do {                                                                                            \
+    int ld_; const float* s_ = tile_src((K), ld_);                                                \
+    PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
+    PF_ONE(4, sr4, s_, ld_) PF_ONE(5, sr5, s_, ld_) PF_ONE(6, sr6, s_, ld_) PF_ONE(7, sr7, s_, ld_) \
+  } while (0)
+#define WRITE_ALL(S)                                                                              \
+  do {                                                                                            \
+    lds_float* wb_ = opaque_w(wbuf + (S) * SLOT);                                                 \
+    PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
+    PB_ONE(4, sr4, wb_) PB_ONE(5, sr5, wb_) PB_ONE(6, sr6, wb_) PB_ONE(7, sr7, wb_)               \
+  } while (0)
+  // column group C of the multiplication with tile k, with its share of the staging traffic
+#define GEMM_CT(C, REG, XF, ACC)                                                                  \
+  if constexpr (NCT > (C)) {                                                                      \
+    if ((C) + 1 < NCT) {                                                                          \
+      _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot)                                          \
+        a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
+    if (do_w_) { PB_ONE(C, REG, wb_) }                                                            \
+    if (do_p_) { PF_ONE(C, REG, ns_, nld_) }                                                      \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].w, (XF)[4 * (C) + 3], (ACC)[ot]); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+#define STAGE(K, XF, ACC)                                                                         \
+  do {                                                                                            \
+    const int k_ = (K);                                                                           \
+    const bool do_w_ = (k_ + 1 < NT) && (k_ != HOLD);                                               \
+    const bool do_p_ = (k_ + 2 < NT) && (k_ != HOLD);                                               \
+    int nld_ = D; const float* ns_ = do_p_ ? tile_src(k_ + 2, nld_) : nullptr;                    \
+    SSTAMP(0);                                                                                    \
+    __syncthreads();                                                                              \
+    SSTAMP(1);                                                                                    \
+    const lds_float* tl_ = opaque(wbuf + slot * SLOT + i * LD + 4 * grp);                         \
+    lds_float* wb_ = opaque_w(wbuf + (slot ^ 1) * SLOT);                                          \
+    float4 a_[2][NOT];                                                                            \
+    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
+    GEMM_CT(0, sr0, XF, ACC) SSTAMP(2); GEMM_CT(1, sr1, XF, ACC) GEMM_CT(2, sr2, XF, ACC) GEMM_CT(3, sr3, XF, ACC) \
+    SSTAMP(3); GEMM_CT(4, sr4, XF, ACC) GEMM_CT(5, sr5, XF, ACC) GEMM_CT(6, sr6, XF, ACC) GEMM_CT(7, sr7, XF, ACC) \
+    SSTAMP(4);                                                                                    \
+    slot ^= 1;                                                                                    \
+    (void)wb_; (void)ns_; (void)nld_;                                                             \
+  } while (0)
+
+
 // One transformer block of one image, inference step: x = h_{g+1} from HBM; writes e_{g+2} and J^T e.
 template <int NCT, int H>
 __device__ __forceinline__ void wide_block_body(const FusedP& p, float* lds, int g, int b) {
@@ -149,70 +215,10 @@ __device__ __forceinline__ void wide_block_body(const FusedP& p, float* lds, int
     const int j = k - 42;
     ldw = 3 * D; return WqkvT + (long long)(j & 1) * TR * 3 * D + (long long)(j >> 1) * D;
   };
-#define PF_ONE(J, REG, SRC, LDW)                                                                  \
-  if constexpr (NST > (J)) {                                                                      \
-    const int f_ = tid + 256 * (J);                                                               \
-    if (NF4 % 256 == 0 || f_ < NF4)                                                               \
-      REG = *reinterpret_cast<const float4*>((SRC) + (long long)(f_ / (D / 4)) * (LDW) + 4 * (f_ % (D / 4))); \
-  }
-#define PB_ONE(J, REG, WB)                                                                        \
-  if constexpr (NST > (J)) {                                                                      \
-    const int f_ = tid + 256 * (J);                                                               \
-    if (NF4 % 256 == 0 || f_ < NF4)                                                               \
-      lds_st4((WB) + (f_ / (D / 4)) * LD + 4 * (f_ % (D / 4)), REG);                              \
-  }
-  // whole-tile forms (prologue, and the restart after the attention backward)
-#define PREFETCH_ALL(K)                                                                           \
-  do {                                                                                            \
-    int ld_; const float* s_ = tile_src((K), ld_);                                                \
-    PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
-    PF_ONE(4, sr4, s_, ld_) PF_ONE(5, sr5, s_, ld_) PF_ONE(6, sr6, s_, ld_) PF_ONE(7, sr7, s_, ld_) \
-  } while (0)
-#define WRITE_ALL(S)                                                                              \
-  do {                                                                                            \
-    lds_float* wb_ = opaque_w(wbuf + (S) * SLOT);                                                 \
-    PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
-    PB_ONE(4, sr4, wb_) PB_ONE(5, sr5, wb_) PB_ONE(6, sr6, wb_) PB_ONE(7, sr7, wb_)               \
-  } while (0)
-  // column group C of the multiplication with tile k, with its share of the staging traffic
-#define GEMM_CT(C, REG, XF, ACC)                                                                  \
-  if constexpr (NCT > (C)) {                                                                      \
-    if ((C) + 1 < NCT) {                                                                          \
-      _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot)                                          \
-        a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
-    }                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
-    if (do_w_) { PB_ONE(C, REG, wb_) }                                                            \
-    if (do_p_) { PF_ONE(C, REG, ns_, nld_) }                                                      \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].w, (XF)[4 * (C) + 3], (ACC)[ot]); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-  }
-  // Stage K: tiles 41 -> 42 straddle the attention backward, whose Q / dO rows take both slots: stage 41
-  // writes nothing (tile 42 waits in the staging registers) and RESTART publishes it afterwards.
+  // tiles 41 -> 42 straddle the attention backward, whose Q / dO rows take both slots: stage HOLD = 41
+  // writes nothing (tile 42 waits in the staging registers) and the restart publishes it afterwards
+  constexpr int NT = 48, HOLD = 41;
   int slot = 0;
-#define STAGE(K, XF, ACC)                                                                         \
-  do {                                                                                            \
-    const int k_ = (K);                                                                           \
-    const bool do_w_ = (k_ + 1 < 48) && (k_ != 41);                                               \
-    const bool do_p_ = (k_ + 2 < 48) && (k_ != 41);                                               \
-    int nld_ = D; const float* ns_ = do_p_ ? tile_src(k_ + 2, nld_) : nullptr;                    \
-    SSTAMP(0);                                                                                    \
-    __syncthreads();                                                                              \
-    SSTAMP(1);                                                                                    \
-    const lds_float* tl_ = opaque(wbuf + slot * SLOT + i * LD + 4 * grp);                         \
-    lds_float* wb_ = opaque_w(wbuf + (slot ^ 1) * SLOT);                                          \
-    float4 a_[2][NOT];                                                                            \
-    _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
-    GEMM_CT(0, sr0, XF, ACC) SSTAMP(2); GEMM_CT(1, sr1, XF, ACC) GEMM_CT(2, sr2, XF, ACC) GEMM_CT(3, sr3, XF, ACC) \
-    SSTAMP(3); GEMM_CT(4, sr4, XF, ACC) GEMM_CT(5, sr5, XF, ACC) GEMM_CT(6, sr6, XF, ACC) GEMM_CT(7, sr7, XF, ACC) \
-    SSTAMP(4);                                                                                    \
-    slot ^= 1;                                                                                    \
-    (void)wb_; (void)ns_; (void)nld_;                                                             \
-  } while (0)
-
   f32x4 acc[NOT];
   PREFETCH_ALL(0);
   WRITE_ALL(0);                    // tile 0 -> slot 0 (visible after stage 0's barrier)
@@ -423,12 +429,146 @@ __device__ __forceinline__ void wide_block_body(const FusedP& p, float* lds, int
     store_row<NCT>(dk, p.BP1 + (long long)g * nl + rowoff, grp);
     WSTAMP(13);
   }
-#undef STAGE
-#undef GEMM_CT
-#undef PREFETCH_ALL
-#undef WRITE_ALL
-#undef PF_ONE
-#undef PB_ONE
+}
+
+// ---- chain: status "forward" (/root/reference/src/decoder_transformer.py:232-241, 488-494) -------------
+// One workgroup walks ONE image through all L blocks on the forward half of the block body (24 tiles per
+// block, the prefetch running across block boundaries): INIT pass and the reconstruction after the weight
+// update, instead of 7 per-op launches per block.  Block g reads its rows from (g == 0 ? xin : xout +
+// (g - 1) stride) and writes them to xout + g stride; stride = 0 with xin == xout walks in place (a lane
+// re-reads only rows it wrote itself).  P / LSE still go to the stash / LDS rows (head_forward writes them;
+// nobody reads them here).
+template <int NCT, int H>
+__device__ __forceinline__ void wide_chain_body(const FusedP& p, float* lds, int b, const float* xin, float* xout, long long stride) {
+  using Cf = WideCfg<NCT>;
+  constexpr int D = Cf::D, M = Cf::M, R = Cf::R, NOT = Cf::NOT, TR = Cf::TR, LD = Cf::LD, SLOT = Cf::SLOT;
+  constexpr int NST = Cf::NST, NF4 = Cf::NF4;
+  constexpr int DH = D / H, QH = DH / 4;
+  constexpr int TPB = 24;                 // forward tiles per block
+  constexpr int HOLD = -1;
+  const int NT = TPB * p.L;
+  const float sc = rsqrtf((float)DH) * CORA_LOG2E;
+
+  float* bufK = lds;
+  float* bufV = lds + SLOT;
+  float* wbuf = lds + 2 * SLOT;
+  float* rowc = lds + 4 * SLOT;
+  float* pb = lds + 4 * SLOT + 512;      // [b1 M | ln2 gamma D | ln2 beta D | b2 D]
+  constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, grp = lane >> 4;
+  const long long rowoff = ((long long)b * 64 + 16 * w + i) * D;
+  float* st_p = p.S_stash + ((long long)b * 64 + 16 * w + i) * (H * 64 + D);   // scratch rows of block 0's stash
+
+  auto tile_src = [&](int k, int& ldw) -> const float* {
+    const int gg = k / TPB, kk = k - gg * TPB;
+    if (kk < 6) { ldw = D; return p.W + p.oWqkv + (long long)gg * 3 * D * D + (long long)kk * TR * D; }
+    if (kk < 8) { ldw = D; return p.W + p.oWo + (long long)gg * D * D + (long long)(kk - 6) * TR * D; }
+    const int mt = (kk - 8) >> 2, j = (kk - 8) & 3;
+    if (j < 2) { ldw = D; return p.W + p.oW1 + (long long)gg * M * D + ((long long)mt * D + j * TR) * D; }
+    ldw = M; return p.W + p.oW2 + (long long)gg * D * M + (long long)(j - 2) * TR * M + (long long)mt * D;
+  };
+  float4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+  int slot = 0;
+  f32x4 acc[NOT];
+  PREFETCH_ALL(0);
+  WRITE_ALL(0);
+  PREFETCH_ALL(1);
+
+  for (int g = 0; g < p.L; ++g) {
+    const float* xrow = (g == 0 ? xin : xout + (long long)(g - 1) * stride) + rowoff;
+    float* urow = xout + (long long)g * stride + rowoff;
+    const int k0 = g * TPB;
+    __syncthreads();                     // the previous block's parameter vectors and K / V are no longer read
+    {
+      constexpr int NP4 = (M + 3 * D) / 4;
+      for (int f = tid; f < NP4; f += 256) {
+        const int o = 4 * f;
+        const float* src = o < M ? p.W + p.ob1 + (long long)g * M + o
+                         : o < M + D ? p.W + p.oLn2g + (long long)g * D + (o - M)
+                         : o < M + 2 * D ? p.W + p.oLn2b + (long long)g * D + (o - M - D)
+                                         : p.W + p.ob2 + (long long)g * D + (o - M - 2 * D);
+        *reinterpret_cast<float4*>(pb + o) = *reinterpret_cast<const float4*>(src);   // visible after the next tile barrier
+      }
+    }
+    float y[R];
+    {
+      float x[R], qkeep[R];
+      load_row<NCT>(x, xrow, grp);
+      float xn[R];
+      {
+        float gm[R], bt[R], xh[R + 1];
+        load_row<NCT>(gm, p.W + p.oLn1g + (long long)g * D, grp);
+        load_row<NCT>(bt, p.W + p.oLn1b + (long long)g * D, grp);
+        ln_row<NCT>(x, gm, bt, xh, xn);
+      }
+      float kf[R];
+      zero_acc<NOT>(acc); STAGE(k0 + 0, xn, acc); unpack_at<NOT>(acc, qkeep, 0);
+      zero_acc<NOT>(acc); STAGE(k0 + 1, xn, acc); unpack_at<NOT>(acc, qkeep, NOT);
+      zero_acc<NOT>(acc); STAGE(k0 + 2, xn, acc); unpack_at<NOT>(acc, kf, 0);
+      zero_acc<NOT>(acc); STAGE(k0 + 3, xn, acc); unpack_at<NOT>(acc, kf, NOT);
+      store_row<NCT>(kf, &bufK[(16 * w + i) * LD], grp);
+      zero_acc<NOT>(acc); STAGE(k0 + 4, xn, acc); unpack_at<NOT>(acc, kf, 0);
+      zero_acc<NOT>(acc); STAGE(k0 + 5, xn, acc); unpack_at<NOT>(acc, kf, NOT);
+      store_row<NCT>(kf, &bufV[(16 * w + i) * LD], grp);
+      __syncthreads();   // K, V of all 64 tokens visible
+      float of[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) of[k] = 0.f;
+      head_forward<LD, 0, QH>(bufK, bufV, qkeep, of, st_p, rowc, sc, i, grp, w);
+      if constexpr (H > 1) head_forward<LD, QH, 2 * QH>(bufK, bufV, qkeep, of, st_p + 64, rowc + 64, sc, i, grp, w);
+      if constexpr (H > 2) head_forward<LD, 2 * QH, 3 * QH>(bufK, bufV, qkeep, of, st_p + 128, rowc + 128, sc, i, grp, w);
+      if constexpr (H > 3) head_forward<LD, 3 * QH, 4 * QH>(bufK, bufV, qkeep, of, st_p + 192, rowc + 192, sc, i, grp, w);
+      zero_acc<NOT>(acc); STAGE(k0 + 6, of, acc); unpack_at<NOT>(acc, y, 0);
+      zero_acc<NOT>(acc); STAGE(k0 + 7, of, acc); unpack_at<NOT>(acc, y, NOT);
+      load_row<NCT>(x, xrow, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) y[k] += x[k];
+    }
+    float zn[R], xr[R];
+    {
+      float gm[R], bt[R], xh[R + 1];
+      load_row<NCT>(gm, pb + PB_LN2G, grp);
+      load_row<NCT>(bt, pb + PB_LN2B, grp);
+      ln_row<NCT>(y, gm, bt, xh, zn);
+    }
+    f32x4 zacc[NCT];
+    zero_acc<NCT>(zacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float am[R];
+      zero_acc<NOT>(acc); STAGE(k0 + 8 + 4 * mt, zn, acc); unpack_at<NOT>(acc, am, 0);
+      zero_acc<NOT>(acc); STAGE(k0 + 9 + 4 * mt, zn, acc); unpack_at<NOT>(acc, am, NOT);
+      {
+        float b1[R];
+        load_row<NCT>(b1, pb + mt * D, grp);
+#pragma unroll
+        for (int k = 0; k < R; k += 2) {
+          f32x2 g2, gp2;
+          cora_gelu_both2((f32x2){am[k] + b1[k], am[k + 1] + b1[k + 1]}, g2, gp2);
+          am[k] = g2.x; am[k + 1] = g2.y;
+        }
+      }
+      if (mt == 3) load_row<NCT>(xr, xrow, grp);     // x again: its latency runs under the last two tiles
+      STAGE(k0 + 10 + 4 * mt, am, zacc);
+      STAGE(k0 + 11 + 4 * mt, am, zacc + NOT);
+    }
+    {
+      float z[R], b2[R];
+      unpack_at<NCT>(zacc, z, 0);
+      load_row<NCT>(b2, pb + PB_B2, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) z[k] += xr[k] + y[k] + b2[k];      // u = x + y + MLP
+      store_row<NCT>(z, urow, grp);
+    }
+  }
+}
+
+template <int NCT, int H>
+__global__ __launch_bounds__(256, 1) void pc_chain_wide_kernel(FusedP p, const float* xin, float* xout, long long stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  wide_chain_body<NCT, H>(p, lds, (int)blockIdx.x, xin, xout, stride);
 }
 
 template <int NCT, int H>
@@ -483,3 +623,39 @@ int launch_fused_wide(const FusedP& p, int L, int D, hipStream_t st) {
   return -1;
 #endif
 }
+
+template <int NCT, int H>
+static int launch_chain_wide_t(const FusedP& p, const float* xin, float* xout, long long stride, hipStream_t st) {
+  static bool attr[64] = {};
+  const size_t sm = (size_t)WideCfg<NCT>::LDS_FLOATS * sizeof(float);
+  if (first_use_on_device(attr)) {
+    if (hipFuncSetAttribute((const void*)pc_chain_wide_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL((pc_chain_wide_kernel<NCT, H>), dim3(p.B), dim3(256), sm, st, p, xin, xout, stride);
+  return 0;
+}
+
+// the L blocks of the status-"forward" chain for every image (see wide_chain_body)
+int launch_chain_wide(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st) {
+  if (L < 1 || p.L != L) return -1;
+  if (D == 128) {
+    switch (p.H) {
+      case 1: return launch_chain_wide_t<8, 1>(p, xin, xout, stride, st);
+      case 2: return launch_chain_wide_t<8, 2>(p, xin, xout, stride, st);
+      case 4: return launch_chain_wide_t<8, 4>(p, xin, xout, stride, st);
+    }
+  } else if (D == 96) {
+    switch (p.H) {
+      case 1: return launch_chain_wide_t<6, 1>(p, xin, xout, stride, st);
+      case 2: return launch_chain_wide_t<6, 2>(p, xin, xout, stride, st);
+      case 4: return launch_chain_wide_t<6, 4>(p, xin, xout, stride, st);
+    }
+  }
+  return -1;
+}
+#undef STAGE
+#undef GEMM_CT
+#undef PREFETCH_ALL
+#undef WRITE_ALL
+#undef PF_ONE
+#undef PB_ONE
