@@ -16,6 +16,7 @@
 //                 lane holds D[i = 4grp+reg][j = c]  (the own row j stays on the lane)
 //   accum   tile  D[cc][j] += sum_i Z[i][cc] W[i][j] : A = Z[i = 4grp+reg][cc = c], B = score regs
 #include "common.h"
+#include "attn_map.h"
 
 #define CH 64  // streamed rows per chunk
 // 16-column output tiles per head; a head dim that is not a multiple of 16 (24 = 96 / 4 of the
@@ -46,11 +47,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // stage rows [r0, r0+CH) x [0,DH) of a [*, ld] matrix (column offset already applied) into LDS
-template <int DH>
+template <int DH, int NTH = 256>
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld, int r0, int nrows) {
   constexpr int LD = DH + 4;
   constexpr int V = DH / 4;  // float4 per row
-  for (int f = threadIdx.x; f < CH * V; f += 256) {
+  for (int f = threadIdx.x; f < CH * V; f += NTH) {
     int row = f / V, c4 = f % V;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + row < nrows) v = *reinterpret_cast<const float4*>(src + (long long)(r0 + row) * ld + 4 * c4);
@@ -140,41 +141,21 @@ __device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const 
     }
 }
 
-template <int V> struct IntC { static constexpr int value = V; };
-// run body(IntC<nvt>) for nvt = 1..4 valid 16-row tiles in the streamed chunk (uniform over the workgroup)
-template <typename F>
-__device__ __forceinline__ void for_valid_tiles(int nvt, F&& body) {
-  if (nvt >= 4) body(IntC<4>{});
-  else if (nvt == 3) body(IntC<3>{});
-  else if (nvt == 2) body(IntC<2>{});
-  else body(IntC<1>{});
-}
-
-__device__ __forceinline__ float grp_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
-}
-__device__ __forceinline__ float grp_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
-                                                       float* __restrict__ lse2, int N, int H, int D) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
+                                                       float* __restrict__ lse2, int nimg, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   AttnSmem2<DH>& sm = *reinterpret_cast<AttnSmem2<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
-  const int img = blockIdx.z, h = blockIdx.y;
+  int rb, h, img;
+  if (!attn_coords((N + 16 * NW - 1) / (16 * NW), H, nimg, rb, h, img)) return;
   const int ld = 3 * D;
   const float* base = qkv + (long long)img * N * ld;
   const float* Q = base + h * DH;
   const float* K = base + D + h * DH;
   const float* V = base + 2 * D + h * DH;
-  const int qrow = blockIdx.x * 64 + 16 * w + c;
+  const int qrow = rb * 16 * NW + 16 * w + c;
   const float sc = rsqrtf((float)DH) * CORA_LOG2E;  // base-2 logits
 
   float qf[DH / 4];
@@ -186,11 +167,11 @@ __global__ __launch_bounds__(256, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const f
 
   // a wave whose 16 query rows all lie past the sequence (the last row block of N = 196 holds 4 rows)
   // only helps staging; empty key tiles of the last chunk are skipped (for_valid_tiles)
-  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
+  const bool wave_active = rb * 16 * NW + 16 * w < N;
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
-    stage_rows<DH>(sm.s1, K, ld, k0, N);
-    stage_rows<DH>(sm.s2, V, ld, k0, N);
+    stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
+    stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
     __syncthreads();
     if (!wave_active) continue;
     for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
@@ -240,15 +221,16 @@ __global__ __launch_bounds__(256, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const f
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
                                                          const float* __restrict__ lse2, const float* __restrict__ dO,
                                                          float* __restrict__ delta, float* __restrict__ dqkv,
-                                                         int N, int H, int D) {
+                                                         int nimg, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   AttnSmem2<DH>& sm = *reinterpret_cast<AttnSmem2<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
-  const int img = blockIdx.z, h = blockIdx.y;
+  int rb, h, img;
+  if (!attn_coords((N + 16 * NW - 1) / (16 * NW), H, nimg, rb, h, img)) return;
   const int ld = 3 * D;
   const float* base = qkv + (long long)img * N * ld;
   const float* Q = base + h * DH;
@@ -256,7 +238,7 @@ __global__ __launch_bounds__(256, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const
   const float* V = base + 2 * D + h * DH;
   const float* dOp = dO + (long long)img * N * D + h * DH;
   const float* Op = O + (long long)img * N * D + h * DH;
-  const int qrow = blockIdx.x * 64 + 16 * w + c;
+  const int qrow = rb * 16 * NW + 16 * w + c;
   const float scale = rsqrtf((float)DH);
   const float sc = scale * CORA_LOG2E;
 
@@ -278,11 +260,11 @@ __global__ __launch_bounds__(256, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const
 #pragma unroll
   for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
+  const bool wave_active = rb * 16 * NW + 16 * w < N;
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
-    stage_rows<DH>(sm.s1, K, ld, k0, N);
-    stage_rows<DH>(sm.s2, V, ld, k0, N);
+    stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
+    stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
     __syncthreads();
     if (!wave_active) continue;
     for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
@@ -312,21 +294,22 @@ __global__ __launch_bounds__(256, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
                                                           const float* __restrict__ dO, const float* __restrict__ delta,
-                                                          float* __restrict__ dqkv, int N, int H, int D) {
+                                                          float* __restrict__ dqkv, int nimg, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   AttnSmem<DH>& sm = *reinterpret_cast<AttnSmem<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
-  const int img = blockIdx.z, h = blockIdx.y;
+  int rb, h, img;
+  if (!attn_coords((N + 16 * NW - 1) / (16 * NW), H, nimg, rb, h, img)) return;
   const int ld = 3 * D;
   const float* base = qkv + (long long)img * N * ld;
   const float* Q = base + h * DH;
   const float* K = base + D + h * DH;
   const float* V = base + 2 * D + h * DH;
   const float* dOp = dO + (long long)img * N * D + h * DH;
-  const int krow = blockIdx.x * 64 + 16 * w + c;
+  const int krow = rb * 16 * NW + 16 * w + c;
   const float scale = rsqrtf((float)DH);
   const float sc = scale * CORA_LOG2E;
 
@@ -340,11 +323,11 @@ __global__ __launch_bounds__(256, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(cons
     dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  const bool wave_active = blockIdx.x * 64 + 16 * w < N;
+  const bool wave_active = rb * 16 * NW + 16 * w < N;
   for (int q0 = 0; q0 < N; q0 += CH) {
     __syncthreads();
-    stage_rows<DH>(sm.s1, Q, ld, q0, N);
-    stage_rows<DH>(sm.s2, dOp, D, q0, N);
+    stage_rows<DH, 64 * NW>(sm.s1, Q, ld, q0, N);
+    stage_rows<DH, 64 * NW>(sm.s2, dOp, D, q0, N);
     if (threadIdx.x < CH) {
       int q = q0 + threadIdx.x;
       long long ri = ((long long)img * N + q) * H + h;
@@ -488,15 +471,35 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
+template <int DH, int NW>
+static int run_fwd_w(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
   size_t sm = sizeof(AttnSmem2<DH>);
   static bool attr_set[64] = {};
   if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   }
-  dim3 grid((N + 63) / 64, H, nimg);
-  hipLaunchKernelGGL((attn_fwd_kernel<DH>), grid, dim3(256), sm, st, qkv, O, lse2, N, H, D);
+  const int nrb = (N + 16 * NW - 1) / (16 * NW);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, NW>), dim3(attn_grid(nrb, H, nimg)), dim3(64 * NW), sm, st, qkv, O, lse2, nimg, N, H, D);
+  return 0;
+}
+template <int DH>
+static int run_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
+  return attn_waves(nimg, N, H, false) == 8 ? run_fwd_w<DH, 8>(qkv, O, lse2, nimg, N, H, D, st)
+                                     : run_fwd_w<DH, 4>(qkv, O, lse2, nimg, N, H, D, st);
+}
+template <int DH, int NW>
+static int run_bwd_w(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
+                     float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+  size_t sm = sizeof(AttnSmem<DH>);
+  static bool attr_set[64] = {};
+  if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  }
+  const int nrb = (N + 16 * NW - 1) / (16 * NW);
+  const dim3 grid(attn_grid(nrb, H, nimg));
+  hipLaunchKernelGGL((attn_bwd_q_kernel<DH, NW>), grid, dim3(64 * NW), sizeof(AttnSmem2<DH>), st, qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<DH, NW>), grid, dim3(64 * NW), sm, st, qkv, lse2, dO, delta, dqkv, nimg, N, H, D);
   return 0;
 }
 template <int DH>
@@ -511,16 +514,8 @@ static int run_bwd(const float* qkv, const float* O, const float* lse2, const fl
     hipLaunchKernelGGL((attn_bwd_small_kernel<DH>), dim3(1, H, nimg), dim3(256), sm4, st, qkv, lse2, dO, dqkv, N, H, D);
     return 0;
   }
-  size_t sm = sizeof(AttnSmem<DH>);
-  static bool attr_set[64] = {};
-  if (sm > 48 * 1024 && first_use_on_device(attr_set)) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  }
-  dim3 grid((N + 63) / 64, H, nimg);
-  hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, dim3(256), sizeof(AttnSmem2<DH>), st, qkv, O, lse2, dO, delta, dqkv, N, H, D);
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, dim3(256), sm, st, qkv, lse2, dO, delta, dqkv, N, H, D);
-  return 0;
+  return attn_waves(nimg, N, H, true) == 8 ? run_bwd_w<DH, 8>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st)
+                                     : run_bwd_w<DH, 4>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st);
 }
 
 #define DISPATCH_DH(dh, CALL)        \

@@ -400,7 +400,9 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   {
     double fl = 14.0 * G * c->B * (double)c->N * c->N * D;   // 7 products (S and dP are recomputed per side)
     KScope s(c, K_ATTN_BWD, fl, 4.0 * rows * 9 * D);
-    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+    if (c->cfg.dtype_mode == 1 && attn_bwd_bf16_supported(c->N, H, D)) {
+      if (launch_attn_bwd_bf16(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward (bf16): launch set-up failed");
+    } else if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
   }
   // dxn = dqkv Wqkv
   p = gemm_base(c, 1); p.groups = G;
