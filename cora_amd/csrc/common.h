@@ -141,6 +141,8 @@ int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const f
                     float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
 // bf16 mode (attn_bf16.hip): the same backward on bf16 MFMA; -1 (nothing launched) where it does not apply
 bool attn_bwd_bf16_supported(int N, int H, int D);
+bool attn_fwd_bf16_supported(int N, int H, int D);
+int launch_attn_fwd_bf16(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st);
 int launch_attn_bwd_bf16(const float* qkv, const float* O, const float* lse2, const float* dO,
                          float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
 

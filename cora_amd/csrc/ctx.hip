@@ -330,7 +330,9 @@ int block_forward(cora_ctx* c, int G, int b0, const float* xin, float* out, int 
   {
     double fl = 4.0 * G * c->B * (double)c->N * c->N * D;
     KScope s(c, K_ATTN_FWD, fl, 4.0 * rows * 4 * D);
-    if (launch_attn_fwd(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention: head dim not supported (need 16,24,32,48,64,96,128)");
+    if (c->cfg.dtype_mode == 1 && attn_fwd_bf16_supported(c->N, H, D)) {
+      if (launch_attn_fwd_bf16(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention (bf16): launch set-up failed");
+    } else if (launch_attn_fwd(c->qkv, c->att, c->lse, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention: head dim not supported (need 16,24,32,48,64,96,128)");
   }
   // y = x + att Wo^T
   p = gemm_base(c); p.groups = G;
