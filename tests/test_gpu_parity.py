@@ -43,6 +43,7 @@ CASES = {
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
+    "n144_h4_headdim16": ((3, 48, 48), 4, 64, 4, 2, 2, 3),     # N = 144: two chunks + one 16-row tile, head dim 16
 }
 
 
@@ -116,7 +117,8 @@ def test_regularisers_and_clipping():
 BF16_TOL = 1e-2
 
 
-BF16_CASES = ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk"]
+BF16_CASES = ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk",
+              "n144_h4_headdim16"]
 
 
 def run_bf16_case(name):
@@ -145,12 +147,32 @@ def test_bf16_opt_in(name):
     """Opt-in bf16 mode (BASELINE.json north_star: "bf16 as an opt-in mode", bar rel <= 1e-2 on final
     vodes, per-step energies and weight gradients; configs[3] names bf16 MFMA for the 224x224 case):
     GEMM operands are rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (two-term split for the
-    forward predictions), accumulation and every stored tensor stay fp32.  Gradients are compared per
+    forward predictions), attention longer than one chunk runs on v_mfma_f32_16x16x16_bf16 (split operands
+    in the forward, plain bf16 in the backward), accumulation and every stored tensor stay fp32.  Gradients are compared per
     tensor against the largest entry of that tensor family, as in the fp32 test."""
     errs = run_bf16_case(name)
     print(name, "bf16 max rel err", max(errs.values()), max(errs, key=errs.get))
     bad = {k: v for k, v in errs.items() if not v <= BF16_TOL}
     assert not bad, f"{name}: bf16 parity failures: {bad}"
+
+
+@pytest.mark.parametrize("rows", ["64", "128", "256"])
+@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16"])
+def test_bf16_attention_workgroup_shapes(name, rows, monkeypatch):
+    """The bf16-MFMA attention kernels (attn_bf16.hip) pick 64 / 128 own rows per workgroup from the launch
+    size (256 = two own tiles per wave is kept for experiments), so the small test shapes would only ever
+    run the 64-row form: force each through CORA_ATTN_BF16_ROWS (read at every launch).  Same bar."""
+    monkeypatch.setenv("CORA_ATTN_BF16_ROWS", rows)
+    errs = run_bf16_case(name)
+    bad = {k: v for k, v in errs.items() if not v <= BF16_TOL}
+    assert not bad, f"{name} rows={rows}: bf16 parity failures: {bad}"
+
+
+@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16"])
+def test_attention_eight_wave_workgroups(name, monkeypatch):
+    """fp32 attention with 8 waves (128 own rows) per workgroup -- chosen by launch size, so forced here."""
+    monkeypatch.setenv("CORA_ATTN_WAVES", "8")
+    run_case(name)
 
 
 @pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4"])
