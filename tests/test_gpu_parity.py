@@ -44,6 +44,9 @@ CASES = {
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
     "n144_h4_headdim16": ((3, 48, 48), 4, 64, 4, 2, 2, 3),     # N = 144: two chunks + one 16-row tile, head dim 16
+    "n144_h2_headdim32": ((3, 48, 48), 4, 64, 2, 1, 2, 2),
+    "n144_h1_headdim96": ((3, 48, 48), 4, 96, 1, 1, 2, 2),     # chunked attention at the wide head dims
+    "n144_h1_headdim128": ((3, 48, 48), 4, 128, 1, 1, 2, 2),
 }
 
 
@@ -118,7 +121,7 @@ BF16_TOL = 1e-2
 
 
 BF16_CASES = ["tiny_2block_h2", "cfg2_shape_B4", "cfg4_shape_B1", "cfg3_shape_B2", "cfg5_video_small", "n36_h2_ragged_chunk",
-              "n144_h4_headdim16"]
+              "n144_h4_headdim16", "n144_h2_headdim32", "n144_h1_headdim96", "n144_h1_headdim128"]
 
 
 def run_bf16_case(name):
@@ -157,7 +160,7 @@ def test_bf16_opt_in(name):
 
 
 @pytest.mark.parametrize("rows", ["64", "128", "256"])
-@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16"])
+@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16", "n144_h1_headdim128"])
 def test_bf16_attention_workgroup_shapes(name, rows, monkeypatch):
     """The bf16-MFMA attention kernels (attn_bf16.hip) pick 64 / 128 own rows per workgroup from the launch
     size (256 = two own tiles per wave is kept for experiments), so the small test shapes would only ever
@@ -168,7 +171,7 @@ def test_bf16_attention_workgroup_shapes(name, rows, monkeypatch):
     assert not bad, f"{name} rows={rows}: bf16 parity failures: {bad}"
 
 
-@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16"])
+@pytest.mark.parametrize("name", ["cfg4_shape_B1", "cfg5_video_small", "n144_h4_headdim16", "n144_h1_headdim128"])
 def test_attention_eight_wave_workgroups(name, monkeypatch):
     """fp32 attention with 8 waves (128 own rows) per workgroup -- chosen by launch size, so forced here."""
     monkeypatch.setenv("CORA_ATTN_WAVES", "8")
