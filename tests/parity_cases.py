@@ -42,7 +42,13 @@ FULL_CASES = {
 }
 
 
-def build_full_case(name: str):
+# the same cases in the opt-in bf16 mode (bar 1e-2): the shapes its bf16 GEMM + bf16 attention kernels serve,
+# with all T chained steps (the 64-token configs run their fused fp32 kernels only in fp32 mode)
+BF16_FULL_CASES = ["cfg4_imagenet224_L6_B2_T10", "cfg5_video16_N1024_L2_B1_T20", "cfg3_12block_D128_H4_B32_T20"]
+BF16_TOL = 1e-2
+
+
+def build_full_case(name: str, compute_dtype: str = "fp32"):
     import cora_amd as ca
     from cora_amd.optim import lr_at
     from cora_amd.params import init_params
@@ -62,7 +68,7 @@ def build_full_case(name: str):
     hp = R.Hyper(l1=mc.intermediate_l1_coeff, l2=mc.intermediate_l2_coeff, use_scaling=mc.use_inference_lr_scaling,
                  scale_base=mc.inference_lr_scale_base, clip_h=mc.h_grad_clip_norm, clip_w=mc.w_grad_clip_norm,
                  momentum=mc.hidden_momentum, wd=mc.weight_decay)
-    model = ca.TransformerDecoder(tc, seed=42, max_T=max(T, 64))
+    model = ca.TransformerDecoder(tc, seed=42, max_T=max(T, 64), compute_dtype=compute_dtype)
     model.positional_embedding = pos
     model.set_weights(W)
     for l, t in enumerate(h):
@@ -75,11 +81,16 @@ def build_full_case(name: str):
                 eta_h=eta_h, eta_w=eta_w, B=B, T=T)
 
 
-def run_full_case(name: str):
-    """-> (rows, info): rows[tensor] = {"err", "floor", "bar"}; info = sizes and timings."""
+def run_full_case(name: str, compute_dtype: str = "fp32"):
+    """-> (rows, info): rows[tensor] = {"err", "floor", "bar"}; info = sizes and timings.
+    compute_dtype "bf16": the opt-in bf16 mode, bar 1e-2 on what north_star names (final vodes, per-step
+    energies, weight gradients) and on final_w_energy / train_mse; the gh* rows (final_h_grad, returned for
+    logging: cancellation noise of e = h - u, the fp32 oracle itself is 2e-2 off on gh0 of the ImageNet shape)
+    are recorded with "bar": None and not held, as in tests/test_gpu_parity.py::test_bf16_opt_in."""
     import time
     import cora_amd as ca
-    c = build_full_case(name)
+    c = build_full_case(name, compute_dtype)
+    tol = BF16_TOL if compute_dtype == "bf16" else TOL
     T, L = c["T"], c["dims"].L
     args = (T, c["x"], c["W"], c["h"], c["pos"], c["dims"], c["hp"], c["eta_h"], c["eta_w"])
     t0 = time.perf_counter()
@@ -98,7 +109,10 @@ def run_full_case(name: str):
         sc = (np.abs(want).max() + 1e-30) if scale is None else scale
         err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / sc)
         floor = float(np.abs(np.asarray(f32, dtype=np.float64) - want).max() / sc)
-        rows[key] = {"err": err, "floor": floor, "bar": max(TOL, 3.0 * floor) if key.startswith("gh") else TOL}
+        bar = max(tol, 3.0 * floor) if key.startswith("gh") else tol
+        if compute_dtype == "bf16" and key.startswith("gh"):
+            bar = None
+        rows[key] = {"err": err, "floor": floor, "bar": bar}
 
     put("energies[T]", tot, ref["energies"], r32["energies"])
     put("layer_energies[T,L+3]", per, ref["layer_energies"], r32["layer_energies"])
@@ -114,7 +128,7 @@ def run_full_case(name: str):
     info = {"config": FULL_CASES[name][0], "overrides": FULL_CASES[name][1], "B": c["B"], "T": T,
             "N": c["dims"].N, "D": c["dims"].D, "H": c["dims"].H, "L": L,
             "oracle_fp64_s": round(t1 - t0, 2), "oracle_fp32_s": round(t2 - t1, 2),
-            "kernel_path": kernel_path,
+            "kernel_path": kernel_path, "compute_dtype": compute_dtype,
             "energy_first_last": [float(ref["energies"][0]), float(ref["energies"][-1])]}
     model.close()
     return rows, info
@@ -122,6 +136,7 @@ def run_full_case(name: str):
 
 def summarise(rows):
     """worst err, worst err/bar, and the tensors whose bar is not the plain 1e-4"""
-    worst = max(rows, key=lambda k: rows[k]["err"] / rows[k]["bar"])
-    relaxed = {k: v for k, v in rows.items() if v["bar"] > TOL}
+    held = {k: v for k, v in rows.items() if v["bar"] is not None}
+    worst = max(held, key=lambda k: held[k]["err"] / held[k]["bar"])
+    relaxed = {k: v for k, v in held.items() if v["bar"] > TOL}
     return worst, relaxed

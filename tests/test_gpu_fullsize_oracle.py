@@ -10,7 +10,7 @@ import os
 
 import pytest
 
-from tests.parity_cases import FULL_CASES, TOL, run_full_case, summarise
+from tests.parity_cases import BF16_FULL_CASES, BF16_TOL, FULL_CASES, TOL, run_full_case, summarise
 
 pytestmark = pytest.mark.gpu
 
@@ -27,3 +27,17 @@ def test_full_size_oracle_parity(name):
     bad = {k: v for k, v in rows.items() if not v["err"] <= v["bar"]}
     assert not bad, f"{name}: parity failures {bad}"
     assert all(v["bar"] == TOL for k, v in rows.items() if not k.startswith("gh"))
+
+
+@pytest.mark.parametrize("name", BF16_FULL_CASES)
+def test_full_size_oracle_parity_bf16(name):
+    """The opt-in bf16 mode at the benchmarked shapes over all T chained steps (small shapes and T <= 5:
+    tests/test_gpu_parity.py::test_bf16_opt_in): ImageNet 224/16 with all 6 blocks (bf16 GEMMs + bf16-MFMA
+    attention, ragged last chunk), the 1024-token video shape (16 chunks) and the 12-block sweep point (per-op
+    path with the one-chunk fp32 attention).  Bar 1e-2 on everything north_star names."""
+    rows, info = run_full_case(name, compute_dtype="bf16")
+    worst, _ = summarise(rows)
+    print(f"bf16 {name}: {info}; worst {worst} {rows[worst]}")
+    bad = {k: v for k, v in rows.items() if v["bar"] is not None and not v["err"] <= v["bar"]}
+    assert not bad, f"{name} (bf16): parity failures {bad}"
+    assert all(v["bar"] == BF16_TOL for k, v in rows.items() if not k.startswith("gh"))
