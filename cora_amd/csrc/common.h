@@ -107,7 +107,9 @@ struct GemmP {
   int a_gelu;            // apply tanh-GELU to A while staging (MLP2 reads the pre-activation)
   int b_gelu;            // same for the B operand (weight-gradient of linear2)
   int bf16;              // opt-in: 1 = operands rounded to bf16 in registers, bf16 MFMA, fp32 accumulate;
-                         // 2 = two-term bf16 split of both operands, three bf16 MFMAs (near-fp32 products)
+                         // 2 = two-term bf16 split of both operands, three bf16 MFMAs (near-fp32 products);
+                         // 3 = three-term split, six MFMAs (fp32-grade products; bf16-staged NT kernel only --
+                         //     every other operand form runs the fp32 kernel)
   float alpha;           // v = alpha * acc (+ bias + pos + res1 + res2)
   const float* bias; long long sBias;
   const float* pos; int posN;
@@ -118,9 +120,10 @@ struct GemmP {
   const float* aux;      // OUT_GELUGRAD: pre-activation a   (ld = ldc)
   float alpha2, l1, l2;
   double* red; int red_stride;   // red[g * red_stride] accumulates energy / sum of squares
-  // bf16 mode: the B operand (a weight) already converted to bf16, hi (and lo for the split form), indexed
-  // like Bw (ctx.hip keeps the copies fresh); null -> B is converted from Bw while staging
-  const unsigned short* Bh; const unsigned short* Bl;
+  // bf16 modes: the B operand (a weight) already converted to bf16 -- hi, second term (split forms) and third
+  // term (three-term form) -- indexed like Bw (ctx.hip keeps the copies fresh); null -> B is converted from
+  // Bw while staging
+  const unsigned short* Bh; const unsigned short* Bl; const unsigned short* B3;
 };
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
@@ -206,8 +209,9 @@ void launch_adamw(const AdamP& p, hipStream_t st);
 // red[0] += sum (clip01(a)-clip01(b))^2
 void launch_mse(const float* a, const float* b, long long n, double* out, hipStream_t st);
 void launch_zero(void* ptr, size_t bytes, hipStream_t st);
-// bf16 copies of n floats: hi = bf16(x), lo = bf16(x - hi) (lo may be null)
-void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st);
+// bf16 copies of n floats: hi = bf16(x), lo = bf16(x - hi), t3 = bf16(x - hi - lo) (lo, t3 may be null)
+void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st,
+                     unsigned short* t3 = nullptr);
 
 // ---- fused per-(block, image) kernel (N = 64, D = 64, H = 1) -----------------------------------------
 struct FusedP {

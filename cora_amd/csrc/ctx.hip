@@ -111,7 +111,8 @@ struct cora_ctx {
   size_t tWqkv = 0, tWo = 0, tW1 = 0, tW2 = 0, tWp = 0, tWout = 0, nWT = 0;
   // bf16 mode: bf16 copies of the weights (hi, lo: forward GEMMs use the split form) and of their transposes
   // (hi only: backward-data GEMMs use plain bf16), refreshed with WT after every weight update
-  unsigned short *Wh = nullptr, *Wl = nullptr, *WTh = nullptr;
+  unsigned short *Wh = nullptr, *Wl = nullptr, *WTh = nullptr;          // bf16 copies of W (hi, second term) and WT (hi)
+  unsigned short *W3 = nullptr, *WTl = nullptr, *WT3 = nullptr;          // dtype_mode 2: third term of W; second, third of WT
   bool fused = false;     // D = 64 fused kernel (inference, STORE and chain modes)
   bool fusedw = false;    // D = 96 / 128 fused kernel (inference step only; learning phase and chain stay per-op)
   bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
@@ -259,7 +260,8 @@ GemmP gemm_base(cora_ctx* c, int kind = 0 /* 0 forward, 1 backward-data, 2 weigh
   // bf16 mode: backward-data and weight-gradient GEMMs take plain bf16 operands (their error is
   // relative to the result); the forward predictions feed e = h - u, which cancels most of u, so
   // they use the split form (measured: plain bf16 there alone costs 2.5e-2 on the 6-block vodes)
-  p.bf16 = (c->cfg.dtype_mode == 1) ? (kind == 0 ? 2 : 1) : 0;
+  // dtype_mode 2 ("bf16x3"): three-term split everywhere, fp32-grade products
+  p.bf16 = (c->cfg.dtype_mode == 1) ? (kind == 0 ? 2 : 1) : (c->cfg.dtype_mode == 2 ? 3 : 0);
   return p;
 }
 
@@ -268,8 +270,13 @@ void run_gemm(cora_ctx* c, const GemmP& p_in, bool ako, bool bko) {
   static const bool no_pre = getenv("CORA_BF16_NO_PRE") != nullptr;   // diagnostic: convert weights while staging
   if (c->Wh && p.bf16 && !ako && !bko && !no_pre) {
     // bf16 mode, weight operand: hand the kernel the copy that is already bf16 (same element offsets)
-    if (p.Bw >= c->W && p.Bw < c->W + c->nW) { p.Bh = c->Wh + (p.Bw - c->W); p.Bl = c->Wl + (p.Bw - c->W); }
-    else if (p.bf16 == 1 && c->WT && p.Bw >= c->WT && p.Bw < c->WT + c->nWT) { p.Bh = c->WTh + (p.Bw - c->WT); p.Bl = nullptr; }
+    if (p.Bw >= c->W && p.Bw < c->W + c->nW) {
+      const size_t o = p.Bw - c->W;
+      p.Bh = c->Wh + o; p.Bl = c->Wl + o; p.B3 = c->W3 ? c->W3 + o : nullptr;
+    } else if (c->WT && p.Bw >= c->WT && p.Bw < c->WT + c->nWT && (p.bf16 == 1 || (p.bf16 == 3 && c->WT3))) {
+      const size_t o = p.Bw - c->WT;
+      p.Bh = c->WTh + o; p.Bl = c->WTl ? c->WTl + o : nullptr; p.B3 = c->WT3 ? c->WT3 + o : nullptr;
+    }
   }
   int kind = ako ? K_GEMM_TN : (bko ? K_GEMM_NN : K_GEMM_NT);
   double fl = 2.0 * p.R * (double)p.O * p.K * p.groups;
@@ -282,7 +289,7 @@ void run_gemm(cora_ctx* c, const GemmP& p_in, bool ako, bool bko) {
 // In bf16 mode the GEMMs read the transposed copy instead -- K-inner, the one operand form the
 // bf16-staged kernel (gemm_bf16.hip) takes.  Sets p.Bw / p.ldb (p.K and p.O already set); returns b_kouter.
 bool bwd_weight(cora_ctx* c, GemmP& p, size_t w_off, size_t wt_off) {
-  if (c->cfg.dtype_mode == 1 && c->WT) { p.Bw = c->WT + wt_off; p.ldb = p.K; return false; }
+  if (c->cfg.dtype_mode != 0 && c->WT) { p.Bw = c->WT + wt_off; p.ldb = p.K; return false; }
   p.Bw = c->W + w_off; p.ldb = p.O;
   return true;
 }
@@ -436,8 +443,8 @@ void refresh_wt(cora_ctx* c) {
   add(c->oW2, c->tW2, D, M, L); add(c->oWp, c->tWp, D, c->P, 1); add(c->oWout, c->tWout, c->P, D, 1);
   launch_transpose_set(t, c->st);
   if (c->Wh) {
-    launch_cvt_bf16(c->W, c->Wh, c->Wl, (long long)c->nW, c->st);
-    launch_cvt_bf16(c->WT, c->WTh, nullptr, (long long)c->nWT, c->st);
+    launch_cvt_bf16(c->W, c->Wh, c->Wl, (long long)c->nW, c->st, c->W3);
+    launch_cvt_bf16(c->WT, c->WTh, c->WTl, (long long)c->nWT, c->st, c->WT3);
   }
 }
 
@@ -740,7 +747,7 @@ const char* cora_last_error(const cora_ctx* ctx) { return ctx ? ctx->err.c_str()
 
 // configuration checks shared by cora_create and cora_forward_static: nullptr = fine
 static const char* check_config(const cora_config* cfg) {
-  if (cfg->dtype_mode != 0 && cfg->dtype_mode != 1) return "dtype_mode: 0 (fp32 MFMA, parity path) or 1 (bf16 MFMA operands, fp32 accumulate and state)";
+  if (cfg->dtype_mode < 0 || cfg->dtype_mode > 2) return "dtype_mode: 0 (fp32 MFMA, parity path), 1 (bf16 MFMA operands, fp32 accumulate and state) or 2 (three-term bf16 split in the GEMMs: fp32-grade products on the bf16 pipe)";
   if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return "non-positive dimension";
   if (cfg->D % cfg->H) return "hidden_size must be divisible by num_heads";
   if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return "D, P and M must be multiples of 4 (16-byte rows)";
@@ -806,17 +813,22 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->fusedw = (!c->fused && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_wide_supported(c->N, c->P, c->D, c->H, c->M) &&
                getenv("CORA_NO_FUSED") == nullptr);
   c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
-  if (c->fused || c->fusedw || cfg->dtype_mode == 1) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
+  if (c->fused || c->fusedw || cfg->dtype_mode != 0) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
     c->nWT = t;
     DA(c->WT, c->nWT);
-    if (cfg->dtype_mode == 1) {
+    if (cfg->dtype_mode != 0) {
       float* tmpb = nullptr;
       DA(tmpb, (long long)(c->nW + 1) / 2 + 4); c->Wh = (unsigned short*)tmpb;
       DA(tmpb, (long long)(c->nW + 1) / 2 + 4); c->Wl = (unsigned short*)tmpb;
       DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WTh = (unsigned short*)tmpb;
+      if (cfg->dtype_mode == 2) {
+        DA(tmpb, (long long)(c->nW + 1) / 2 + 4); c->W3 = (unsigned short*)tmpb;
+        DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WTl = (unsigned short*)tmpb;
+        DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WT3 = (unsigned short*)tmpb;
+      }
     }
     if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
   }

@@ -253,7 +253,10 @@ void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
   if (!a_kouter && !b_kouter && !inreg && gemm_bf16_nt_supported(p)) { launch_gemm_bf16_nt(p, st); return; }
   dim3 grid((p.R + BM - 1) / BM, (p.O + BN - 1) / BN, p.groups * p.splitk);
   const bool bk32 = (p.K % 32 == 0 && p.splitk == 1);
-  if (p.bf16 == 2) {
+  if (p.bf16 == 3) {            // three-term mode outside the bf16-staged kernel: plain fp32 MFMA
+    if (bk32) launch_bk<32, 0>(p, a_kouter, b_kouter, grid, st);
+    else launch_bk<16, 0>(p, a_kouter, b_kouter, grid, st);
+  } else if (p.bf16 == 2) {
     if (bk32) launch_bk<32, 2>(p, a_kouter, b_kouter, grid, st);
     else launch_bk<16, 2>(p, a_kouter, b_kouter, grid, st);
   } else if (p.bf16 == 1) {
@@ -274,6 +277,6 @@ void launch_gemm_multi_tn(const GemmMulti& m_in, hipStream_t st) {
     total += ((p.R + BM - 1) / BM) * ((p.O + BN - 1) / BN) * p.groups * p.splitk;
   }
   m.start[m.n] = total;
-  if (m.p[0].bf16) hipLaunchKernelGGL((gemm_multi_tn_kernel<1>), dim3(total), dim3(256), 0, st, m);
+  if (m.p[0].bf16 == 1 || m.p[0].bf16 == 2) hipLaunchKernelGGL((gemm_multi_tn_kernel<1>), dim3(total), dim3(256), 0, st, m);
   else hipLaunchKernelGGL((gemm_multi_tn_kernel<0>), dim3(total), dim3(256), 0, st, m);
 }

@@ -6,7 +6,10 @@
 // v_mfma_f32_32x32x16_bf16 operand (8 k values per lane) and no conversion work sits between the
 // MFMAs.  SPLIT = 1 keeps the two-term split x = hi + lo of both operands (three MFMAs, products good
 // to ~2^-16): the forward predictions feed e = h - u, which cancels most of u, and plain bf16 there
-// costs 2.5e-2 on the 6-block vodes (gemm.hip).
+// costs 2.5e-2 on the 6-block vodes (gemm.hip).  SPLIT = 2 (dtype_mode = 2, "bf16x3") keeps three terms
+// x = hi + mid + lo of both operands and the six products whose weight is above 2^-24 (hi*hi, hi*mid, mid*hi,
+// mid*mid, hi*lo, lo*hi): fp32-grade products from the bf16 pipe, which at six MFMAs still has 2.7 x the
+// rate of v_mfma_f32_32x32x2_f32.
 //
 // Both operands are K-inner ("NT"): activations [row][k] and weights [out][in].  The backward-data
 // GEMMs, whose weight is K-outer as stored, read the transposed weight copies the context keeps in
@@ -66,6 +69,13 @@ __device__ __forceinline__ bf16x4 to_bf16_lo(const float4 v, const bf16x4 h) {
   l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
   return l;
 }
+// third term: bf16(x - hi - mid); both subtractions are exact in fp32
+__device__ __forceinline__ bf16x4 to_bf16_3(const float4 v, const bf16x4 h, const bf16x4 m) {
+  bf16x4 l;
+  l[0] = (__bf16)((v.x - (float)h[0]) - (float)m[0]); l[1] = (__bf16)((v.y - (float)h[1]) - (float)m[1]);
+  l[2] = (__bf16)((v.z - (float)h[2]) - (float)m[2]); l[3] = (__bf16)((v.w - (float)h[3]) - (float)m[3]);
+  return l;
+}
 
 #ifndef BF_OCC
 #define BF_OCC 2
@@ -76,6 +86,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? TM * LDR : 8];
   __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT ? TN * LDR : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 A3[SPLIT == 2 ? TM * LDR : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 B3[SPLIT == 2 ? TN * LDR : 8];
 
   // hardware deals consecutive workgroup ids round-robin over the 8 XCDs: XCD x works through the
   // contiguous range [x * per, (x + 1) * per) of the tile list (column tile fastest)
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
   // staging: float4 #f of a 128 x TK tile = row f / KQ, k quad f % KQ; thread t takes #t + 256 i (row t / KQ + RSTEP i)
   const int srow = tid / KQ, skq = tid % KQ;
   float4 ra[NV], rb[BPRE ? 1 : NV];
-  uint4 pbh[2], pbl[2];
+  uint4 pbh[2], pbl[2], pb3[2];
   auto load_tiles = [&](int k0) {
     const int gk = k0 + 4 * skq;
     const bool kok = gk < p.K;
@@ -115,6 +127,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
         const long long off = (long long)g * p.sB + (long long)gc * p.ldb + gkb;
         pbh[i] = ok ? *reinterpret_cast<const uint4*>(p.Bh + off) : make_uint4(0u, 0u, 0u, 0u);
         if (SPLIT) pbl[i] = ok ? *reinterpret_cast<const uint4*>(p.Bl + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (SPLIT == 2) pb3[i] = ok ? *reinterpret_cast<const uint4*>(p.B3 + off) : make_uint4(0u, 0u, 0u, 0u);
       }
     } else {
 #pragma unroll
@@ -132,7 +145,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       const int o = (srow + RSTEP * i) * LDR + 4 * skq;
       const bf16x4 h = to_bf16(v);
       *reinterpret_cast<bf16x4*>(&Ah[o]) = h;
-      if (SPLIT) *reinterpret_cast<bf16x4*>(&Al[o]) = to_bf16_lo(v, h);
+      if (SPLIT) {
+        const bf16x4 m = to_bf16_lo(v, h);
+        *reinterpret_cast<bf16x4*>(&Al[o]) = m;
+        if (SPLIT == 2) *reinterpret_cast<bf16x4*>(&A3[o]) = to_bf16_3(v, h, m);
+      }
     }
     if (BPRE) {
 #pragma unroll
@@ -141,6 +158,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
         const int o = (f >> 2) * LDR + 8 * (f & 3);
         *reinterpret_cast<uint4*>(&Bh[o]) = pbh[i];
         if (SPLIT) *reinterpret_cast<uint4*>(&Bl[o]) = pbl[i];
+        if (SPLIT == 2) *reinterpret_cast<uint4*>(&B3[o]) = pb3[i];
       }
     } else {
 #pragma unroll
@@ -149,7 +167,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
         const int o = (srow + RSTEP * i) * LDR + 4 * skq;
         const bf16x4 h = to_bf16(v);
         *reinterpret_cast<bf16x4*>(&Bh[o]) = h;
-        if (SPLIT) *reinterpret_cast<bf16x4*>(&Bl[o]) = to_bf16_lo(v, h);
+        if (SPLIT) {
+          const bf16x4 m = to_bf16_lo(v, h);
+          *reinterpret_cast<bf16x4*>(&Bl[o]) = m;
+          if (SPLIT == 2) *reinterpret_cast<bf16x4*>(&B3[o]) = to_bf16_3(v, h, m);
+        }
       }
     }
   };
@@ -179,7 +201,27 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const bf16x8*>(&Ah[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
       for (int n = 0; n < WN; ++n) bh[n] = *reinterpret_cast<const bf16x8*>(&Bh[boff + 32 * n * LDR + 16 * kk]);
-      if (SPLIT) {
+      if (SPLIT == 2) {   // smallest terms first: hi * lo, lo * hi, mid * mid
+        bf16x8 a3[2], b3[WN];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a3[m] = *reinterpret_cast<const bf16x8*>(&A3[aoff + 32 * m * LDR + 16 * kk]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) b3[n] = *reinterpret_cast<const bf16x8*>(&B3[boff + 32 * n * LDR + 16 * kk]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) bl[n] = *reinterpret_cast<const bf16x8*>(&Bl[boff + 32 * n * LDR + 16 * kk]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[m], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], b3[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+          }
+      } else if (SPLIT) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
@@ -235,9 +277,14 @@ void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st) {
   const int ntiles = tx * ty * p.groups;
   const dim3 grid(((ntiles + 7) / 8) * 8);
   // pre-converted weights need 16-byte aligned octets of k
-  const bool pre = p.Bh != nullptr && (p.bf16 != 2 || p.Bl != nullptr) && p.K % 8 == 0 && p.ldb % 8 == 0 && p.sB % 8 == 0 &&
-                   ((uintptr_t)p.Bh % 16) == 0 && (p.bf16 != 2 || ((uintptr_t)p.Bl % 16) == 0);
-  if (p.bf16 == 2) {
+  const int terms = p.bf16;     // 1 plain, 2 two-term split, 3 three-term split
+  const bool pre = p.Bh != nullptr && (terms < 2 || p.Bl != nullptr) && (terms < 3 || p.B3 != nullptr) && p.K % 8 == 0 &&
+                   p.ldb % 8 == 0 && p.sB % 8 == 0 && ((uintptr_t)p.Bh % 16) == 0 && (terms < 2 || ((uintptr_t)p.Bl % 16) == 0) &&
+                   (terms < 3 || ((uintptr_t)p.B3 % 16) == 0);
+  if (terms == 3) {
+    if (pre) hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, false>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+  } else if (terms == 2) {
     if (pre) hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
     else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, false>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
   } else {

@@ -540,7 +540,7 @@ void launch_zero(void* ptr, size_t bytes, hipStream_t st) {   // bytes % 16 == 0
 // hi = bf16(x) (round to nearest even), lo = bf16(x - hi): the same two conversions the GEMM kernel applies
 // to an operand it converts itself while staging, so both forms give bit-identical products.
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi,
-                                                       unsigned short* __restrict__ lo, long long n) {
+                                                       unsigned short* __restrict__ lo, unsigned short* __restrict__ t3, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float x = src[i];
     const __bf16 h = (__bf16)x;
@@ -548,12 +548,16 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
     if (lo) {
       const __bf16 l = (__bf16)(x - (float)h);
       lo[i] = __builtin_bit_cast(unsigned short, l);
+      if (t3) {
+        const __bf16 t = (__bf16)((x - (float)h) - (float)l);
+        t3[i] = __builtin_bit_cast(unsigned short, t);
+      }
     }
   }
 }
-void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st) {
+void launch_cvt_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, hipStream_t st, unsigned short* t3) {
   long long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, hi, lo, n);
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, hi, lo, t3, n);
 }

@@ -140,9 +140,10 @@ class TransformerDecoder:
     def __init__(self, config: TransformerConfig, *, seed: int = 42, device: int = 0, max_T: int = 64,
                  compute_dtype: str = "fp32"):
         _lib.load()                      # fail loudly if the HIP library is missing
-        if compute_dtype not in ("fp32", "bf16"):
-            raise ValueError("compute_dtype must be 'fp32' (parity path) or 'bf16' (opt-in: bf16 MFMA operands)")
-        self._dtype_mode = 1 if compute_dtype == "bf16" else 0
+        if compute_dtype not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("compute_dtype must be 'fp32' (parity path), 'bf16' (opt-in: bf16 MFMA operands) or "
+                             "'bf16x3' (opt-in: three-term bf16 split in the GEMMs, fp32-grade products)")
+        self._dtype_mode = {"fp32": 0, "bf16": 1, "bf16x3": 2}[compute_dtype]
         self.config = config
         self.device = device
         self.max_T = max_T

@@ -47,9 +47,13 @@ typedef struct cora_config {
   int32_t Himg;       /* image height                                            */
   int32_t Wimg;       /* image width                                             */
   int32_t F;          /* frames (1 for images)                                   */
-  int32_t dtype_mode; /* 0 = fp32 MFMA (parity path); 1 = opt-in bf16 MFMA: GEMM operands rounded to
-                       * bf16 in registers (two-term split for the forward predictions), fp32
-                       * accumulate, all state fp32 (per-op path only).                        */
+  int32_t dtype_mode; /* 0 = fp32 MFMA (parity path); 1 = opt-in bf16 MFMA: GEMM and (sequences longer
+                       * than 64 tokens) attention operands rounded to bf16 on their way into LDS,
+                       * two-term split for the forward predictions, fp32 accumulate, all state fp32
+                       * (per-op path only; bar 1e-2); 2 = opt-in "bf16x3": every K-inner GEMM takes
+                       * both operands as three bf16 terms and keeps the six products above 2^-24
+                       * (fp32-grade products from the bf16 pipe; per-op path, attention fp32; held
+                       * to the fp32 bars).                                                     */
   int32_t use_scaling;   /* use_inference_lr_scaling (:449-453)                  */
   float   scale_base;    /* inference_lr_scale_base (:308-350)                   */
   float   l1;            /* intermediate_l1_coeff (pcx/predictive_coding/_energy.py:61-68) */

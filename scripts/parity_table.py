@@ -39,6 +39,13 @@ def main():
         table["cases"]["small/" + name] = {"info": {"shape": list(map(str, shape))}, "worst": {worst: rows[worst]},
                                            "n_tensors": len(rows), "above_1e-4_bar": sorted(relaxed), "rows": rows}
         print("small/" + name, "worst", worst, rows[worst], "relaxed", len(relaxed), flush=True)
+    for name in small.BF16X3_CASES:   # dtype_mode 2: held to the fp32 bars
+        errs, floor = small.run_case(name, return_floor=True, compute_dtype="bf16x3")
+        rows = {k: {"err": v, "floor": floor[k], "bar": small.bar_for(k, floor[k])} for k, v in errs.items()}
+        worst, relaxed = summarise(rows)
+        table["cases"]["bf16x3/" + name] = {"info": {"shape": list(map(str, small.CASES[name])), "mode": "dtype_mode = 2 (three-term bf16 split GEMMs)"},
+                                            "worst": {worst: rows[worst]}, "n_tensors": len(rows), "above_1e-4_bar": sorted(relaxed), "rows": rows}
+        print("bf16x3/" + name, "worst", worst, rows[worst], "relaxed", len(relaxed), flush=True)
     for name in small.BF16_CASES:
         errs = small.run_bf16_case(name)
         rows = {k: {"err": v, "floor": None, "bar": small.BF16_TOL} for k, v in errs.items()}

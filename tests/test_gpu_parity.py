@@ -50,11 +50,11 @@ CASES = {
 }
 
 
-def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=False, **kw):
+def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=False, compute_dtype="fp32", **kw):
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
     case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000, l1=l1, l2=l2, clip_h=clip_h, clip_w=clip_w, **kw)
-    model, optim_w, optim_h = build_model(case)
+    model, optim_w, optim_h = build_model(case, compute_dtype=compute_dtype)
     eta = [0.095] * T
     args = (T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], eta, 1e-3)
     ref = R.train_on_batch(*args)
@@ -157,6 +157,19 @@ def test_bf16_opt_in(name):
     print(name, "bf16 max rel err", max(errs.values()), max(errs, key=errs.get))
     bad = {k: v for k, v in errs.items() if not v <= BF16_TOL}
     assert not bad, f"{name}: bf16 parity failures: {bad}"
+
+
+BF16X3_CASES = ["tiny_2block_h2", "cfg2_shape_B4", "cfg3_shape_B2", "cfg4_shape_B1", "cfg5_video_small", "n36_h2_ragged_chunk",
+                "d96_h4_headdim24", "n144_h1_headdim128"]
+
+
+@pytest.mark.parametrize("name", BF16X3_CASES)
+def test_bf16x3_mode_holds_the_fp32_bar(name):
+    """compute_dtype="bf16x3" (dtype_mode 2): every K-inner GEMM of the per-op path takes both operands as three
+    bf16 terms (hi + mid + lo = the fp32 value to 2^-24) and keeps the six products above 2^-24 -- fp32-grade
+    products from the bf16 matrix pipe; attention, accumulation and state stay fp32.  Held to the SAME bars as
+    the fp32 path (plain 1e-4; 1e-5 on the AdamW check), not to the bf16 mode's 1e-2."""
+    run_case(name, compute_dtype="bf16x3")
 
 
 @pytest.mark.parametrize("rows", ["64", "128", "256"])
