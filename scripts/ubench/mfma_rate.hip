@@ -1,89 +1,79 @@
-// Microbenchmark: cycles per v_mfma_f32_16x16x4_f32 from ONE wave per SIMD (256-thread block per CU),
-// 4 interleaved accumulators, operands in registers; variants add LDS reads / VALU between the MFMAs.
+// Throughput of the MFMA forms the attention / fused kernels use or could use (gfx950): a grid that fills
+// every SIMD several times over (2048 workgroups of 4 waves), four independent accumulators per wave,
+// aggregate TFLOP/s from HIP events (workgroup placement decides per-wave rates, so only the aggregate is used).
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/ubench/mfma_rate.hip -o scripts/bin/mfma_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc, int iters) {
-  __shared__ float lds[64 * 132];
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int j = tid; j < 64 * 132; j += 256) lds[j] = (float)(j % 7) * 0.25f;
-  __syncthreads();
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KIND>
+__global__ __launch_bounds__(256) void rate_kernel(float* out, unsigned long long* cyc, int iters) {
+  // four accumulators with different operands, so the compiler cannot fold them into one chain
   f32x4 acc[4];
-  for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0, 0, 0, 0};
-  float b[4] = {1.0f + lane, 0.5f, 0.25f, 2.0f};
-  float4 av[4];
-  const float* tl = lds + (lane & 15) * 132 + 4 * (lane >> 4);
-  for (int ot = 0; ot < 4; ++ot) av[ot] = *reinterpret_cast<const float4*>(tl + 16 * ot * 132);
-  unsigned long long t0, t1;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
-  if (VAR == 2 || VAR == 4) {
-    // ping-pong operand sets, no copies: NR ds_read_b128 per 16 MFMAs
-    float4 bv[4];
-    for (int ot = 0; ot < 4; ++ot) bv[ot] = av[ot];
-    constexpr int NR = (VAR == 2) ? 4 : 2;
-    for (int it = 0; it < iters; it += 2) {
-#define GROUP(CUR, NXT, IT)                                                                      \
-      _Pragma("unroll") for (int ot = 0; ot < NR; ++ot) NXT[ot] = *reinterpret_cast<const float4*>(tl + 16 * ot * 132 + 16 * (((IT) + 1) & 7)); \
-      __builtin_amdgcn_sched_barrier(0);                                                         \
-      _Pragma("unroll") for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(CUR[ot].x, b[0], acc[ot], 0, 0, 0); \
-      _Pragma("unroll") for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(CUR[ot].y, b[1], acc[ot], 0, 0, 0); \
-      _Pragma("unroll") for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(CUR[ot].z, b[2], acc[ot], 0, 0, 0); \
-      _Pragma("unroll") for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(CUR[ot].w, b[3], acc[ot], 0, 0, 0); \
-      __builtin_amdgcn_sched_barrier(0);
-      GROUP(av, bv, it)
-      GROUP(bv, av, it + 1)
-    }
-  } else
+  f32x16 big[4];
+  for (int i = 0; i < 4; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 16; ++j) big[i][j] = 0.f;
+  }
+  float a[4], b = 0.5f;
+  s16x4 a4[4], b4 = {3, 2, 1, (short)threadIdx.x};
+  bf16x8 a8[4], b8;
+  for (int i = 0; i < 4; ++i) {
+    a[i] = 1.0f + threadIdx.x * 1e-3f + i;
+    a4[i] = (s16x4){(short)(threadIdx.x + i), 1, 2, (short)i};
+    for (int j = 0; j < 8; ++j) a8[i][j] = (__bf16)(float)(i + j + threadIdx.x % 3);
+  }
+  for (int j = 0; j < 8; ++j) b8[j] = (__bf16)(float)(j + 1);
   for (int it = 0; it < iters; ++it) {
-    float4 nv[4];
-    if (VAR == 3) { for (int ot = 0; ot < 4; ++ot) { nv[ot] = av[ot]; asm volatile("" : "+v"(nv[ot].x), "+v"(nv[ot].y), "+v"(nv[ot].z), "+v"(nv[ot].w)); } }
-    if (VAR == 1) {
-      for (int ot = 0; ot < 4; ++ot) nv[ot] = *reinterpret_cast<const float4*>(tl + 16 * ot * 132 + 16 * ((it + 1) & 7));
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b, acc[i], 0, 0, 0);
+      if (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4[i], b4, acc[i], 0, 0, 0);
+      if (KIND == 2) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], b8, acc[i], 0, 0, 0);
+      if (KIND == 3) big[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b, big[i], 0, 0, 0);
+      if (KIND == 4) big[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8, big[i], 0, 0, 0);
     }
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot].x, b[0], acc[ot], 0, 0, 0);
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot].y, b[1], acc[ot], 0, 0, 0);
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot].z, b[2], acc[ot], 0, 0, 0);
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot].w, b[3], acc[ot], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (VAR == 1 || VAR == 3) for (int ot = 0; ot < 4; ++ot) av[ot] = nv[ot];
   }
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
-  float s = 0;
-  for (int a = 0; a < 4; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
-  out[blockIdx.x * 256 + tid] = s;
-  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+  (void)cyc;
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int j = 0; j < 16; ++j) s += big[i][j];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-int main() {
+
+template <int KIND>
+static void run(const char* name, double flop_per_inst) {
   float* out; unsigned long long* cyc;
-  const int nb = 256, iters = 4000;
-  hipMalloc(&out, nb * 256 * 4); hipMalloc(&cyc, nb * 8);
-  std::vector<unsigned long long> h(nb);
-  for (int var = 0; var < 5; ++var) {
-    for (int blocks : {256}) {
-      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-      for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(e0);
-        if (var == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
-        else if (var == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
-        else if (var == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
-        else if (var == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
-        else hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-      }
-      float ms; hipEventElapsedTime(&ms, e0, e1);
-      hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
-      double c = 0; for (int i = 0; i < blocks; ++i) c += (double)h[i]; c /= blocks;
-      printf("variant %d blocks %3d: %.1f cycles per MFMA (s_memtime), kernel %.3f ms -> %.2f ns per MFMA -> implied clock %.2f GHz, %.1f TFLOP/s chip-equivalent\n",
-             var, blocks, c / (16.0 * iters), ms, ms * 1e6 / (16.0 * iters), (c / (16.0 * iters)) / (ms * 1e6 / (16.0 * iters)),
-             blocks * 4.0 * 16.0 * iters * 2048 / (ms * 1e-3) / 1e12);
-    }
-  }
+  hipMalloc(&out, 2048 * 256 * sizeof(float)); hipMalloc(&cyc, 8);
+  const int iters = 1500;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((rate_kernel<KIND>), dim3(2048), dim3(256), 0, 0, out, cyc, 100);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((rate_kernel<KIND>), dim3(2048), dim3(256), 0, 0, out, cyc, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double inst = 16.0 * iters;                      // per wave
+  const double tflops = flop_per_inst * inst * 2048 * 4 / (ms * 1e-3) / 1e12;
+  // per SIMD: 2048 * 4 waves / 1024 SIMDs = 8 waves' instructions share one pipe
+  // 8192 waves, 8 per SIMD, 16 MFMAs per loop trip (with 4 per trip the loop branch costs the 16x16x4 form 17 %)
+  printf("%-28s %.3f ms  %.1f TFLOP/s aggregate  %.2f ns per instruction per SIMD\n", name, ms, tflops, ms * 1e6 / (inst * 8));
+  (void)c;
+  hipFree(out); hipFree(cyc);
+}
+
+int main() {
+  run<0>("v_mfma_f32_16x16x4_f32", 2.0 * 16 * 16 * 4);
+  run<1>("v_mfma_f32_16x16x16_bf16", 2.0 * 16 * 16 * 16);
+  run<2>("v_mfma_f32_16x16x32_bf16", 2.0 * 16 * 16 * 32);
+  run<3>("v_mfma_f32_32x32x2_f32", 2.0 * 32 * 32 * 2);
+  run<4>("v_mfma_f32_32x32x16_bf16", 2.0 * 32 * 32 * 16);
   return 0;
 }
