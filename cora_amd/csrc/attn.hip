@@ -59,6 +59,38 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld,
   }
 }
 
+// the same staging in two halves (registers in between) for the 8-wave workgroups: the next chunk's global
+// loads are in flight while the workgroup computes on the current one; 512 threads make it 3 float4 per
+// thread and matrix pair at head dim 48, which the 4-wave form could not afford (it lost occupancy)
+template <int DH, int NTH>
+struct StageF {
+  static constexpr int LD = DH + 4, V = DH / 4, NF = CH * V, NI = (2 * NF + NTH - 1) / NTH;
+  float4 r[NI];
+  __device__ __forceinline__ void load(const float* src0, int ld0, const float* src1, int ld1, int r0, int nrows) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int f2 = it * NTH + (int)threadIdx.x;
+      r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f2 >= 2 * NF) continue;
+      const int m = f2 >= NF, f = m ? f2 - NF : f2;
+      const int row = r0 + f / V, c4 = f % V;
+      const float* src = m ? src1 : src0;
+      const int ld = m ? ld1 : ld0;
+      if (row < nrows) r[it] = *reinterpret_cast<const float4*>(src + (long long)row * ld + 4 * c4);
+    }
+  }
+  __device__ __forceinline__ void store(float* dst0, float* dst1) const {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int f2 = it * NTH + (int)threadIdx.x;
+      if (f2 >= 2 * NF) continue;
+      const int m = f2 >= NF, f = m ? f2 - NF : f2;
+      float* dst = m ? dst1 : dst0;
+      *reinterpret_cast<float4*>(&dst[(f / V) * LD + 4 * (f % V)]) = r[it];
+    }
+  }
+};
+
 // own-row fragment.  Which k an MFMA step contracts is free as long as the A lane and the B lane agree,
 // so for head dims that are a multiple of 16 step (j, t) takes k = 16 j + 4 grp + t: a lane's fragment is
 // DH/16 contiguous float4 (f[4 j + t] = X[row][16 j + 4 grp + t]) and the streamed side reads one
@@ -143,7 +175,7 @@ __device__ __forceinline__ void accum_tiles(f32x4* acc, const float* lds, const 
 
 // ---------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, DH <= 48 ? 6 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? (NW == 8 ? 5 : 6) : 1) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ O,
                                                        float* __restrict__ lse2, int nimg, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   AttnSmem2<DH>& sm = *reinterpret_cast<AttnSmem2<DH>*>(smem_raw);
@@ -168,11 +200,18 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 6 : 1) void attn_fwd_kernel(con
   // a wave whose 16 query rows all lie past the sequence (the last row block of N = 196 holds 4 rows)
   // only helps staging; empty key tiles of the last chunk are skipped (for_valid_tiles)
   const bool wave_active = rb * 16 * NW + 16 * w < N;
+  constexpr bool PRE = (NW == 8);
+  StageF<DH, 64 * NW> stg;
+  if (PRE) stg.load(K, ld, V, ld, 0, N);
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
-    stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
-    stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
+    if (PRE) stg.store(sm.s1, sm.s2);
+    else {
+      stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
+      stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
+    }
     __syncthreads();
+    if (PRE && k0 + CH < N) stg.load(K, ld, V, ld, k0 + CH, N);
     if (!wave_active) continue;
     for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
       constexpr int NVT = decltype(nv)::value;
@@ -222,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 6 : 1) void attn_fwd_kernel(con
 
 // ---------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? (NW == 8 ? 4 : 5) : 1) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
                                                          const float* __restrict__ lse2, const float* __restrict__ dO,
                                                          float* __restrict__ delta, float* __restrict__ dqkv,
                                                          int nimg, int N, int H, int D) {
@@ -261,11 +300,18 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(c
   for (int ct = 0; ct < NT16(DH); ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool wave_active = rb * 16 * NW + 16 * w < N;
+  constexpr bool PRE = (NW == 8);
+  StageF<DH, 64 * NW> stg;
+  if (PRE) stg.load(K, ld, V, ld, 0, N);
   for (int k0 = 0; k0 < N; k0 += CH) {
     __syncthreads();
-    stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
-    stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
+    if (PRE) stg.store(sm.s1, sm.s2);
+    else {
+      stage_rows<DH, 64 * NW>(sm.s1, K, ld, k0, N);
+      stage_rows<DH, 64 * NW>(sm.s2, V, ld, k0, N);
+    }
     __syncthreads();
+    if (PRE && k0 + CH < N) stg.load(K, ld, V, ld, k0 + CH, N);
     if (!wave_active) continue;
     for_valid_tiles((N - k0 + 15) >> 4, [&](auto nv) {
       constexpr int NVT = decltype(nv)::value;
@@ -295,7 +341,7 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 5 : 1) void attn_bwd_q_kernel(c
 
 // ---------------------------------------------------------------------------------------------
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+__global__ __launch_bounds__(64 * NW, DH <= 48 ? (NW == 8 ? 3 : 4) : 1) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
                                                           const float* __restrict__ dO, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int nimg, int N, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -324,10 +370,16 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(
   }
 
   const bool wave_active = rb * 16 * NW + 16 * w < N;
+  constexpr bool PRE = (NW == 8);
+  StageF<DH, 64 * NW> stg;
+  if (PRE) stg.load(Q, ld, dOp, D, 0, N);
   for (int q0 = 0; q0 < N; q0 += CH) {
     __syncthreads();
-    stage_rows<DH, 64 * NW>(sm.s1, Q, ld, q0, N);
-    stage_rows<DH, 64 * NW>(sm.s2, dOp, D, q0, N);
+    if (PRE) stg.store(sm.s1, sm.s2);
+    else {
+      stage_rows<DH, 64 * NW>(sm.s1, Q, ld, q0, N);
+      stage_rows<DH, 64 * NW>(sm.s2, dOp, D, q0, N);
+    }
     if (threadIdx.x < CH) {
       int q = q0 + threadIdx.x;
       long long ri = ((long long)img * N + q) * H + h;
@@ -335,6 +387,7 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? 4 : 1) void attn_bwd_kv_kernel(
       sm.rowc[CH + threadIdx.x] = (q < N) ? delta[ri] : 0.f;
     }
     __syncthreads();
+    if (PRE && q0 + CH < N) stg.load(Q, ld, dOp, D, q0 + CH, N);
     if (!wave_active) continue;
     for_valid_tiles((N - q0 + 15) >> 4, [&](auto nv) {
       constexpr int NVT = decltype(nv)::value;

@@ -47,11 +47,11 @@ __device__ __forceinline__ float grp_sum(float v) {
   return v;
 }
 
-// Waves per workgroup: 8 (128 own rows, the streamed chunks staged half as often per own row) when the
-// sequence is longer than a chunk and the launch still gives every CU two such workgroups, else 4.  Measured
-// (fp32 kernels): video16 (N = 1024) forward 253 -> 247 us, backward 886 -> 847 us; cfg 4 (N = 196, two
-// ragged row blocks of 128) forward 322 -> 304 us but backward 1 033 -> 1 053 us, so short sequences keep
-// 4 waves in the backward.
+// Waves per workgroup: 8 (128 own rows, the streamed chunks staged half as often per own row, and the next
+// chunk prefetched into registers under the compute) when the sequence is longer than a chunk and the launch
+// still gives every CU two such workgroups, else 4.  Measured (fp32 kernels): video16 (N = 1024) forward
+// 253 -> 230 us, backward 886 -> 796 us; cfg 4 (N = 196, two ragged row blocks of 128) forward 322 -> 303 us but
+// backward 1 033 -> 1 094 us, so short sequences keep 4 waves in the backward.
 static inline int attn_waves(int nimg, int N, int H, bool bwd) {
   if (const char* e = getenv("CORA_ATTN_WAVES")) { int v = atoi(e); if (v == 4 || v == 8) return v; }
   if (N <= 64) return 4;
