@@ -13,6 +13,8 @@ bash scripts/pmc_traffic.sh 12block --config 12block > gpurun_out/r2_traffic_12b
 cp gpurun_out/pmc_traffic_12block.json gpurun_out/r2_pmc_traffic_12block.json
 { echo "# cfg 2 (6block, B=200)"; bash scripts/pmc_sq.sh cfg2; echo "# 12block (D=128, H=4, L=12, B=200)"; bash scripts/pmc_sq.sh 12block --config 12block; } > gpurun_out/r2_sq_counters.txt
 # cfg 4's shape at B=64 on the per-op path, fp32 against the bf16 mode (kernel stats + bench lines), video16 lines
+timeout -k 10 300 python3 bench.py --config imagenet224 --steps 3 --warmup 1 --no-cpu-baseline --no-extra --dtype bf16x3 > gpurun_out/r2_imagenet224_bf16x3_bench_line.json 2>/dev/null
+timeout -k 10 60 scripts/bin/mfma_rate > gpurun_out/r2_mfma_rate.txt
 for dt in fp32 bf16; do
   bash scripts/prof_stats.sh r2i224$dt --config imagenet224 --dtype $dt --steps 2 --warmup 1 --no-extra > gpurun_out/r2_stats_i224_$dt.txt
   cp gpurun_out/stats_r2i224$dt.csv gpurun_out/r2_imagenet224_${dt}_kernel_stats.csv
