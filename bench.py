@@ -165,7 +165,8 @@ def dry_run_rank(args, rank, world):
 
 
 # ---- one measured workload ------------------------------------------------------------------------------
-def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, dist, profile=True):
+def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, dist, profile=True, dtype=None):
+    dtype = dtype or args.dtype
     import dataclasses
     import torch
     import cora_amd as ca
@@ -183,7 +184,7 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
     def build(backend):
         """Model + data-parallel binding.  backend: None (one GPU), "rccl" (collectives inside the library's
         graphs) or "torch" (step split at the exchange point, per-shard clip)."""
-        model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=args.dtype)
+        model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=dtype)
         h0 = (0.01 * np.random.default_rng(4321 + rank).standard_normal((B, model.N, model.P))).astype(np.float32)
         model.init_vodes(B, h0=h0)
         optim_w, optim_h = ca.make_optimizers(mc, model, total_train_steps=steps + warmup)
@@ -274,7 +275,7 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
 
     res = None
     if rank == 0:
-        bf16 = args.dtype == "bf16"
+        bf16 = dtype == "bf16"
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_FP32_MATRIX_TFLOPS
         value = world * B * T * steps / elapsed
         S = flops_per_image_step(model.N, model.P, model.D, model.L)
@@ -409,6 +410,18 @@ def main():
         if extra is not None:
             extra["steps"], extra["warmup"] = esteps, ewarm
 
+    extra4 = None
+    if extra is not None and world == 1 and args.dtype == "fp32":
+        # BASELINE config 4's shape (ImageNet 224/16 preset, its own batch size) on the per-op path: fp32 against the
+        # opt-in bf16 mode, three steps each -- the "bf16 mode >= 2 x fp32" figure, measured by the driver's own run
+        mc4 = __import__("cora_amd").MODEL_CONFIGS["imagenet224"]
+        extra4 = {}
+        for dt in ("fp32", "bf16"):
+            m4 = measure(args, "imagenet224", {}, mc4.batch_size, args.T, 3, 1, rank, local_rank, world, dist, dtype=dt)
+            extra4[dt] = {k: m4[k] for k in ("workload", "value", "ms_per_step", "whole_step_mfma_frac", "kernel_ms_per_inference_step")}
+            extra4[dt].update(steps=3, warmup=1, batch=mc4.batch_size)
+        extra4["bf16_over_fp32"] = extra4["bf16"]["value"] / extra4["fp32"]["value"]
+
     if rank == 0:
         r = main_res
         mc, tc = r.pop("mc"), r.pop("tc")
@@ -438,6 +451,8 @@ def main():
                 "workload", "value", "ms_per_step", "steps", "warmup", "whole_step_mfma_frac", "roofline",
                 "infer_only_images_steps_per_s", "algorithmic_flops_per_image_step", "kernel_ms_per_inference_step",
                 "dp_mode")}}
+        if extra4 is not None:
+            result["extra"]["cfg4"] = extra4
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(mc, tc, B, r["T"])
         else:
