@@ -218,9 +218,18 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, const int bx, const in
 #ifndef GEMM_WAVES
 #define GEMM_WAVES 4
 #endif
+// Tile order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (one L2 each), so the
+// 1-D grid is cut into 8 contiguous runs of the tile list, one per XCD, with the COLUMN tile fastest: the
+// O / 64 workgroups that read one 128-row tile of A run back to back on one XCD and all but the first find it
+// in that L2 (with the row tile fastest they were R / 128 launches apart and A came back from HBM / MALL once
+// per column tile).  tx, ty = row / column tiles, nz = groups * splitk; surplus workgroups of the rounded-up
+// grid return at once.
 template <int BK, bool AKO, bool BKO, int BF16>
-__global__ __launch_bounds__(256, GEMM_WAVES) void gemm_kernel(GemmP p) {
-  gemm_body<BK, AKO, BKO, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+__global__ __launch_bounds__(256, GEMM_WAVES) void gemm_kernel(GemmP p, int tx, int ty, int ntiles) {
+  const int per = (ntiles + 7) >> 3;
+  const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (lin >= ntiles) return;
+  gemm_body<BK, AKO, BKO, BF16>(p, (lin / ty) % tx, lin % ty, lin / (ty * tx));
 }
 
 // Several independent TN problems (the weight-gradient contractions of one batch: different shapes,
@@ -239,11 +248,13 @@ __global__ __launch_bounds__(256, 5) void gemm_multi_tn_kernel(GemmMulti m) {
 }
 
 template <int BK, int BF16>
-static void launch_bk(const GemmP& p, bool ako, bool bko, dim3 grid, hipStream_t st) {
-  if (!ako && !bko) hipLaunchKernelGGL((gemm_kernel<BK, false, false, BF16>), grid, dim3(256), 0, st, p);
-  else if (!ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, false, true, BF16>), grid, dim3(256), 0, st, p);
-  else if (ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, true, true, BF16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<BK, true, false, BF16>), grid, dim3(256), 0, st, p);
+static void launch_bk(const GemmP& p, bool ako, bool bko, dim3 g3, hipStream_t st) {
+  const int tx = (int)g3.x, ty = (int)g3.y, ntiles = tx * ty * (int)g3.z;
+  const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8));
+  if (!ako && !bko) hipLaunchKernelGGL((gemm_kernel<BK, false, false, BF16>), grid, dim3(256), 0, st, p, tx, ty, ntiles);
+  else if (!ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, false, true, BF16>), grid, dim3(256), 0, st, p, tx, ty, ntiles);
+  else if (ako && bko) hipLaunchKernelGGL((gemm_kernel<BK, true, true, BF16>), grid, dim3(256), 0, st, p, tx, ty, ntiles);
+  else hipLaunchKernelGGL((gemm_kernel<BK, true, false, BF16>), grid, dim3(256), 0, st, p, tx, ty, ntiles);
 }
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st) {
