@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r2_parity_table.json")
-    from tests.parity_cases import BF16_FULL_CASES, FULL_CASES, TOL, run_full_case, summarise
+    from tests.parity_cases import BF16_FULL_CASES, BF16X3_FULL_CASES, FULL_CASES, TOL, run_full_case, summarise
     from tests import test_gpu_parity as small
     table = {"bar_rule": "plain 1e-4 on vodes (h*), energies, weight gradients (gw*), final_w_energy, train_mse; "
                          "max(1e-4, 3 x fp32-oracle floor) on final_h_grad (gh*) only; 1e-5 on the AdamW kernel check; bf16/* cases: 1e-2; "
@@ -31,6 +31,12 @@ def main():
         table["cases"]["bf16/" + name] = {"info": info, "worst": {worst: rows[worst]}, "n_tensors": len(rows),
                                           "above_1e-4_bar": [], "rows": rows}
         print("bf16/" + name, info, "worst", worst, rows[worst], flush=True)
+    for name in BF16X3_FULL_CASES:
+        rows, info = run_full_case(name, compute_dtype="bf16x3")
+        worst, relaxed = summarise(rows)
+        table["cases"]["bf16x3/" + name] = {"info": info, "worst": {worst: rows[worst]}, "n_tensors": len(rows),
+                                            "above_1e-4_bar": sorted(relaxed), "rows": rows}
+        print("bf16x3/" + name, info, "worst", worst, rows[worst], flush=True)
     for name in small.CASES:
         errs, floor = small.run_case(name, return_floor=True)
         rows = {k: {"err": v, "floor": floor[k], "bar": small.bar_for(k, floor[k])} for k, v in errs.items()}

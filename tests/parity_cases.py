@@ -46,6 +46,8 @@ FULL_CASES = {
 # with all T chained steps (the 64-token configs run their fused fp32 kernels only in fp32 mode)
 BF16_FULL_CASES = ["cfg4_imagenet224_L6_B2_T10", "cfg5_video16_N1024_L2_B1_T20", "cfg3_12block_D128_H4_B32_T20"]
 BF16_TOL = 1e-2
+# dtype_mode 2 (three-term bf16 split in the per-op GEMMs, fp32-grade products) at full size, held to the fp32 bars
+BF16X3_FULL_CASES = ["cfg2_6block_B200_T20", "cfg3_12block_D128_H4_B32_T20", "cfg4_imagenet224_L6_B2_T10"]
 
 
 def build_full_case(name: str, compute_dtype: str = "fp32"):

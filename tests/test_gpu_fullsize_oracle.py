@@ -10,7 +10,7 @@ import os
 
 import pytest
 
-from tests.parity_cases import BF16_FULL_CASES, BF16_TOL, FULL_CASES, TOL, run_full_case, summarise
+from tests.parity_cases import BF16_FULL_CASES, BF16_TOL, BF16X3_FULL_CASES, FULL_CASES, TOL, run_full_case, summarise
 
 pytestmark = pytest.mark.gpu
 
@@ -41,3 +41,15 @@ def test_full_size_oracle_parity_bf16(name):
     bad = {k: v for k, v in rows.items() if v["bar"] is not None and not v["err"] <= v["bar"]}
     assert not bad, f"{name} (bf16): parity failures {bad}"
     assert all(v["bar"] == BF16_TOL for k, v in rows.items() if not k.startswith("gh"))
+
+
+@pytest.mark.parametrize("name", BF16X3_FULL_CASES)
+def test_full_size_oracle_parity_bf16x3(name):
+    """compute_dtype="bf16x3" (per-op path in every shape) at the benchmarked sizes and T: the same bars as the
+    fp32 path -- plain 1e-4; final_h_grad max(1e-4, 3 x fp32-oracle floor)."""
+    rows, info = run_full_case(name, compute_dtype="bf16x3")
+    worst, relaxed = summarise(rows)
+    print(f"bf16x3 {name}: {info}; worst {worst} {rows[worst]}; {len(relaxed)} of {len(rows)} tensors above the plain 1e-4 bar")
+    bad = {k: v for k, v in rows.items() if not v["err"] <= v["bar"]}
+    assert not bad, f"{name} (bf16x3): parity failures {bad}"
+    assert all(v["bar"] == TOL for k, v in rows.items() if not k.startswith("gh"))
