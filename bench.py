@@ -10,8 +10,18 @@ Inputs are resident in HBM when the timed region starts (x is a device tensor).
 
 Workload of the headline line: BASELINE.json configs[1], the 6-block PC-ViT (64 tokens, fp32, T=20) at
 B=200 images per GPU (weak scaling, the default) or, with --global-batch G, G images sharded over the
-ranks (strong scaling: what north_star / configs[2] describe).  The 12-block sweep point named in the
-same metric (D=128, H=4, L=12) is measured in the same run and reported under "extra"."cfg3".
+ranks (strong scaling: what north_star / configs[2] describe).  With N > 1 BOTH scalings are measured in
+the same run and reported under "scalings" (the top-level fields are the one the flags select).
+
+Timing (SURVEY 8(d)): W untimed warm-up calls, then K calls bracketed by barrier + device synchronisation;
+every call is also timed on its own (perf_counter around the synchronising call, MAX over ranks per call).
+`value` = B_total * T / MEDIAN call time; `ms_per_step` is the mean over the bracket (the contract's K-step
+region), `ms_per_step_median/min/max` sit next to it.
+
+"extra" (N = 1 unless noted): cfg3 = the canonical 12-block sweep point (also at N > 1); cfg3_grid = all nine
+(D, H) points of sweeps/sweep_12block_comprehensive.yaml; cfg4 / cfg5 = the ImageNet-preset and 16-frame video
+shapes in fp32 and in the opt-in bf16 mode; small_batch = cfg 2 / cfg 3 at B = 25 / 50 / 100 (what one GPU of
+a 8 / 4 / 2-GPU strong-scaling run of the reference's batch of 200 would see).
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -23,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,11 +44,41 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16 MFMA dense (the 5 PF headline figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
+REFERENCE_BATCH = 200             # /root/reference/src/config.py:474, sweeps/sweep_12block_comprehensive.yaml:15-16
+
+DTYPE_NAMES = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
+               "bf16x3": "f32 as three bf16 terms per GEMM operand / f32 accumulate"}
 
 
 def flops_per_image_step(N, P, D, L):
     """S = 8 N P D + L (48 N D^2 + 12 N^2 D)."""
     return 8.0 * N * P * D + L * (48.0 * N * D * D + 12.0 * N * N * D)
+
+
+# ---- watchdog: a rank that makes no progress exits non-zero instead of waiting for a peer forever ----------
+_progress = [time.time()]
+
+
+def tick():
+    _progress[0] = time.time()
+
+
+def start_watchdog():
+    """A rank whose peer died (or fell out of a collective) would otherwise sit in hipStreamSynchronize until the
+    launcher's overall deadline.  Every call of the measured loops ticks; no tick for CORA_BENCH_STALL_S seconds
+    (default 240) ends this process with exit code 75, and the launcher (ours or torch.distributed.run) then stops
+    the other ranks."""
+    limit = float(os.environ.get("CORA_BENCH_STALL_S", "240"))
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            if time.time() - _progress[0] > limit:
+                sys.stderr.write(f"[bench] rank {os.environ.get('RANK', '0')}: no progress for {limit:.0f} s -- "
+                                 "a peer rank is gone or a collective is stuck; exiting 75\n")
+                sys.stderr.flush()
+                os._exit(75)
+    threading.Thread(target=watch, daemon=True).start()
 
 
 def cpu_baseline(mc, tc, B, T, seconds_budget=20.0):
@@ -61,9 +102,11 @@ def cpu_baseline(mc, tc, B, T, seconds_budget=20.0):
                  wd=mc.weight_decay)
     eta = [mc.peak_lr_hidden] * T
     R.train_on_batch(1, x, W, h, pos, dims, hp, eta[:1], mc.peak_lr_weights, dtype=torch.float32)  # warm
+    tick()
     n, t0 = 0, time.perf_counter()
     while True:
         R.train_on_batch(T, x, W, h, pos, dims, hp, eta, mc.peak_lr_weights, dtype=torch.float32)
+        tick()
         n += 1
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 8:
@@ -76,8 +119,8 @@ def cpu_baseline(mc, tc, B, T, seconds_budget=20.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50, help="timed calls (SURVEY 8(d): >= 50)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up calls (SURVEY 8(d): >= 10)")
     ap.add_argument("--config", default="6block")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's batch_size)")
     ap.add_argument("--global-batch", type=int, default=None,
@@ -87,7 +130,10 @@ def parse_args(argv=None):
     ap.add_argument("--num-heads", type=int, default=None)
     ap.add_argument("--num-blocks", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 12-block (cfg 3) measurement")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no cfg3 / grid / cfg4 / cfg5 / small-batch legs)")
+    ap.add_argument("--sweep-grid", dest="sweep_grid", action="store_true", default=None,
+                    help="measure all nine (D, H) points of the 12-block sweep grid (default: on at N = 1 for the 6block line)")
+    ap.add_argument("--no-sweep-grid", dest="sweep_grid", action="store_false")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = parity path (the headline number); bf16 = opt-in bf16-MFMA mode; bf16x3 = opt-in "
                          "three-term bf16 split in the per-op GEMMs (fp32-grade products; priced against the fp32 peak)")
@@ -98,7 +144,8 @@ def parse_args(argv=None):
                     help="N > 1: 'rccl' = collectives inside the captured graphs (cora_step_dist), "
                          "'torch' = step split at the exchange point, torch.distributed all-reduce")
     ap.add_argument("--dry-run-launch", action="store_true",
-                    help="rank processes only rendezvous (gloo) and report: exercises the launcher without a GPU")
+                    help="rank processes only rendezvous (gloo) and report: exercises the launcher and the shape of "
+                         "the N > 1 line without a GPU")
     return ap.parse_args(argv)
 
 
@@ -112,7 +159,8 @@ def _free_port():
 def launch_ranks(n: int) -> int:
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as
     torch.distributed.run would set them).  The parent never initialises HIP; children are started as
-    new processes (no fork of a GPU process, no exec after GPU init).  Rank 0's stdout is ours."""
+    new processes (no fork of a GPU process, no exec after GPU init).  Rank 0's stdout is ours.  A rank that
+    stalls ends itself (start_watchdog), and one dead rank makes the launcher stop the others."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -122,7 +170,7 @@ def launch_ranks(n: int) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    deadline = time.time() + 3000
+    deadline = time.time() + 1500
     try:
         while procs and any(p.poll() is None for p in procs):
             time.sleep(0.2)
@@ -147,19 +195,72 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+# ---- the JSON line (pure functions: the CPU tests build an N > 1 line from synthetic measurements) ---------
+def scaling_entry(res, world, scaling):
+    """One measured scaling of the data-parallel step: what `scalings.weak` / `scalings.strong` hold."""
+    return {"scaling": scaling, "value": res["value"], "unit": "images*T-steps/s", "ms_per_step": res["ms_per_step"],
+            "ms_per_step_median": res["ms_per_step_median"], "ms_per_step_min": res["ms_per_step_min"],
+            "ms_per_step_max": res["ms_per_step_max"], "steps": res["steps"], "warmup": res["warmup"],
+            "config": {"workload": res["workload"], "global_batch": world * res["per_gpu_batch"],
+                       "per_gpu_batch": res["per_gpu_batch"], "T": res["T"],
+                       "parallelism": parallelism_name(world, res["dp_mode"])},
+            "whole_step_mfma_frac": res["whole_step_mfma_frac"]}
+
+
+def parallelism_name(world, dp_mode):
+    return f"dp{world}" + ("" if world == 1 and dp_mode == "single" else f" ({dp_mode})")
+
+
+def build_line(args, world, main, strong, scalings, rccl_world):
+    """The contract's JSON object from the headline measurement `main` (+ optional sections added by the caller)."""
+    line = {
+        "metric": "PC inference images x T-steps/sec (node)", "value": main["value"], "unit": "images*T-steps/s",
+        "n_gpus": world, "steps": main["steps"], "warmup": main["warmup"],
+        "ms_per_step": main["ms_per_step"], "ms_per_step_median": main["ms_per_step_median"],
+        "ms_per_step_min": main["ms_per_step_min"], "ms_per_step_max": main["ms_per_step_max"],
+        "timing": "value = global_batch * T / MEDIAN per-call time (perf_counter around each synchronising call, MAX over "
+                  "ranks per call); ms_per_step = mean over the barrier-bracketed K-call region",
+        "value_from_mean": main["value_from_mean"],
+        "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": DTYPE_NAMES[args.dtype], "data": "synthetic",
+        "config": {"workload": main["workload"], "global_batch": world * main["per_gpu_batch"], "T": main["T"],
+                   "parallelism": parallelism_name(world, main["dp_mode"]), "rccl_world_size": rccl_world},
+    }
+    if scalings:
+        line["scalings"] = scalings
+    return line
+
+
 def dry_run_rank(args, rank, world):
-    """Launcher rehearsal (CPU, gloo): rendezvous, barrier, MAX over ranks, one JSON line from rank 0."""
+    """Launcher rehearsal (CPU, gloo): rendezvous, barrier, MAX over ranks, and rank 0 prints a line with the
+    SHAPE of the real N > 1 line (both scalings, built by the same build_line / scaling_entry) from synthetic
+    timings -- marked "dry_run", no throughput claim."""
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    B = (args.global_batch // world) if args.global_batch else (args.batch or 200)
+    strong = args.global_batch is not None
+    B = (args.global_batch // world) if strong else (args.batch or REFERENCE_BATCH)
+
+    def fake(b):
+        ms = float(t.item())
+        return {"value": world * b * 20 / (ms * 1e-3), "value_from_mean": world * b * 20 / (ms * 1e-3), "ms_per_step": ms,
+                "ms_per_step_median": ms, "ms_per_step_min": ms, "ms_per_step_max": ms, "steps": args.steps, "warmup": args.warmup,
+                "workload": "dry run (no GPU work)", "per_gpu_batch": b, "T": 20, "dp_mode": "dry-run", "whole_step_mfma_frac": None}
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "world_observed": dist.get_world_size(),
-                          "max_over_ranks": float(t.item()), "scaling": "strong" if args.global_batch else "weak",
-                          "per_gpu_batch": B, "global_batch": B * world}), flush=True)
+        main = fake(B)
+        scalings = None
+        if world > 1:
+            scalings = {"weak": scaling_entry(fake(args.batch or REFERENCE_BATCH), world, "weak")}
+            gb = args.global_batch or REFERENCE_BATCH
+            if gb % world == 0:
+                scalings["strong"] = scaling_entry(fake(gb // world), world, "strong")
+        line = build_line(args, world, main, strong, scalings, dist.get_world_size())
+        line.update({"dry_run": True, "world_observed": dist.get_world_size(), "max_over_ranks": float(t.item()),
+                     "per_gpu_batch": B, "global_batch": B * world})
+        print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -180,10 +281,13 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
     rng = np.random.default_rng(1234 + rank)
     x_host = rng.uniform(0, 1, (B,) + tuple(tc.image_shape)).astype(np.float32)
     force_dp = os.environ.get("CORA_FORCE_DP") == "1"     # exercise the N>1 code path on one GPU
+    tick()
 
     def build(backend):
         """Model + data-parallel binding.  backend: None (one GPU), "rccl" (collectives inside the library's
-        graphs) or "torch" (step split at the exchange point, per-shard clip)."""
+        graphs) or "torch" (step split at the exchange point, per-shard clip).  Whether RCCL could be bound
+        inside the library is agreed over the torch group BEFORE any step runs (a rank that fell back alone
+        would leave its peers inside a collective)."""
         model = ca.TransformerDecoder(tc, seed=42, device=local_rank, max_T=max(T, 64), compute_dtype=dtype)
         h0 = (0.01 * np.random.default_rng(4321 + rank).standard_normal((B, model.N, model.P))).astype(np.float32)
         model.init_vodes(B, h0=h0)
@@ -194,11 +298,20 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
             from cora_amd.dist import DataParallel
             exact = args.clip_mode == "exact"
             if backend == "rccl":
+                bound = 1
                 try:
                     dp = DataParallel(model, B, exact_clip=exact, backend="rccl")
-                except Exception as e:       # RCCL could not be bound inside the library: say so, use the split step
-                    print(f"[bench] in-library RCCL unavailable ({e}); falling back to the torch.distributed path", file=sys.stderr)
-                    backend = "torch"
+                except Exception as e:       # RCCL could not be bound inside the library on this rank
+                    print(f"[bench] rank {rank}: in-library RCCL unavailable ({e})", file=sys.stderr)
+                    bound = 0
+                if dist is not None and dist.is_initialized() and world > 1:
+                    flag = torch.tensor([bound], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    bound = int(flag.item())
+                if not bound:
+                    print("[bench] falling back to the torch.distributed data-parallel path on every rank", file=sys.stderr)
+                    model.close()
+                    return build("torch")
             if backend == "torch":
                 exact = False                # the split step's exact mode is a host round trip per inference step
                 dp = DataParallel(model, B, exact_clip=False, backend="torch")
@@ -225,61 +338,58 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
             _lib.check(lib.cora_wgrad(ctx, C.byref(out)), ctx)
             w = dp.allreduce()
             _lib.check(lib.cora_apply_wgrad(ctx, eta_w, C.c_float(1.0 / (B * w)), C.byref(out)), ctx)
+        tick()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        tick()
 
-    # warm-up; if the in-library RCCL step fails on any rank (e.g. a collective the runtime will not run under a
-    # graph), every rank rebuilds on the torch.distributed path instead of losing the run
-    failed = 0
-    try:
-        for _ in range(warmup):
-            one_step()
-    except _lib.CoraError as e:
-        if dp is None or not dp.in_library:
-            raise
-        failed = 1
-        print(f"[bench] rank {rank}: in-library RCCL step failed ({e})", file=sys.stderr)
-    if dist is not None and dp is not None and dp.in_library:
-        flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        failed = int(flag.item())
-    if failed:
-        print("[bench] falling back to the torch.distributed data-parallel path (per-shard clip)", file=sys.stderr)
-        model.close()
-        model, dp, mode = build("torch")
-        ctx = model._ctx
-        for _ in range(warmup):
-            one_step()
+    # Warm-up.  In-library RCCL: the first call runs eagerly, then the ranks agree (over the torch group, before any
+    # replay) on graph replay vs eager collectives.  A step that fails here is an error, not a reason to fall back:
+    # the peers may already be inside a collective, and the watchdog / launcher end the run.
+    for k in range(max(warmup, 1)):
+        one_step()
+        if k == 0 and dp is not None and dp.in_library:
+            dp.agree_on_graphs(model, T)
     barrier()
-    t0 = time.perf_counter()
+    per_call = np.zeros(steps, dtype=np.float64)
     infer_ms = 0.0
     trace = []
-    for _ in range(steps):
-        one_step()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        c0 = time.perf_counter()
+        one_step()                       # ends with a stream synchronisation: the call time is the device time + host
+        per_call[k] = time.perf_counter() - c0
         infer_ms += out.infer_ms
         trace.append((out.final_h_energy, out.final_w_energy, out.train_mse))
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor(np.concatenate([[elapsed], per_call]), dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = t.cpu().numpy()
+        elapsed, per_call = float(t[0]), t[1:]
     if os.environ.get("CORA_TRACE") == "1":
         print("trace:", trace, file=sys.stderr)
     timing_build = "CORA_HIP_LIB" in os.environ      # diagnostic libraries may compute garbage on purpose
     if not timing_build and (not np.isfinite(out.final_h_energy) or not np.isfinite(out.train_mse)):
         raise SystemExit(f"non-finite energy / mse in the timed region: {trace}")
+    if dp is not None and dp.in_library:
+        mode += ":" + dp.step_mode(model)            # "graph" (collectives replayed as graph nodes) or "eager"
 
     res = None
     if rank == 0:
         bf16 = dtype == "bf16"
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_FP32_MATRIX_TFLOPS
-        value = world * B * T * steps / elapsed
+        med = float(np.median(per_call))
+        value = world * B * T / med
         S = flops_per_image_step(model.N, model.P, model.D, model.L)
-        res = {"value": value, "ms_per_step": 1e3 * elapsed / steps, "per_gpu_batch": B, "T": T,
+        res = {"value": value, "value_from_mean": world * B * T * steps / elapsed,
+               "ms_per_step": 1e3 * elapsed / steps, "ms_per_step_median": 1e3 * med,
+               "ms_per_step_min": 1e3 * float(per_call.min()), "ms_per_step_max": 1e3 * float(per_call.max()),
+               "steps": steps, "warmup": max(warmup, 1), "per_gpu_batch": B, "T": T, "kernel_path": model.kernel_path(),
                "workload": f"{cfg_name} PC-ViT train_on_batch: N={model.N} tokens, P={model.P}, D={model.D}, H={model.H}, "
                            f"L={model.L}, B={B}/GPU, T={T} inference steps + weight update + recon",
                "infer_only_images_steps_per_s": world * B * T * steps / (infer_ms * 1e-3),
@@ -326,6 +436,7 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
             res["inference_step_kernel_ms_total"] = sum(v["ms"] for v in kinds.values()) / reps
     model.close()
     del x_dev
+    tick()
     return res
 
 
@@ -336,8 +447,8 @@ def offline_traffic(roof, cfg_name, B, over):
     if over or B != 200 or roof.get("kernel") != "pc_block_fused":
         return
     # (file, kernel-name prefix) per benchmarked configuration
-    table = {"6block": (("r2_pmc_traffic.json", "r1_pmc_traffic.json"), "void pc_block_fused_kernel<0"),
-             "12block": (("r2_pmc_traffic_12block.json",), "void pc_block_wide2_kernel")}
+    table = {"6block": (("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"), "void pc_block_fused_kernel<0"),
+             "12block": (("r3_pmc_traffic_12block.json", "r2_pmc_traffic_12block.json",), "void pc_block_wide2_kernel")}
     if cfg_name not in table:
         return
     files, prefix = table[cfg_name]
@@ -351,6 +462,13 @@ def offline_traffic(roof, cfg_name, B, over):
             roof["traffic"] = 1024.0 * (2.0 * tj[key]["FETCH_SIZE_per_launch_KB"] + tj[key]["WRITE_SIZE_per_launch_KB"])
             roof["traffic_source"] = f"profiles/{fn} (rocprofv3 PMC, offline)"
             return
+
+
+BRIEF = ("workload", "value", "ms_per_step", "ms_per_step_median", "steps", "warmup", "whole_step_mfma_frac", "kernel_path")
+
+
+def brief(res, *more):
+    return {k: res[k] for k in BRIEF + more if k in res}
 
 
 def main():
@@ -379,6 +497,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
+    tick()
+    start_watchdog()
     dist = None
     force_dp = os.environ.get("CORA_FORCE_DP") == "1"
     if world > 1 or force_dp:
@@ -387,6 +507,7 @@ def main():
         if force_dp and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        tick()
 
     over = {k: v for k, v in (("hidden_size", args.hidden_size), ("num_heads", args.num_heads),
                               ("num_blocks", args.num_blocks)) if v is not None}
@@ -400,42 +521,84 @@ def main():
         B = args.batch or mc0.batch_size
     if (B * 64) % 4:
         raise SystemExit("per-GPU batch too ragged")
+    ctx_args = (rank, local_rank, world, dist)
+    headline = args.config == "6block" and not over
+    extras_on = not args.no_extra and headline
 
-    main_res = measure(args, args.config, over, B, args.T, args.steps, args.warmup, rank, local_rank, world, dist)
-    extra = None
-    if not args.no_extra and not over and args.config == "6block":
+    main_res = measure(args, args.config, over, B, args.T, args.steps, args.warmup, *ctx_args)
+
+    # N > 1: the other scaling of the same workload in the same run (weak = the config's batch on every GPU,
+    # strong = the reference's batch of 200 sharded over the ranks).  Decided from the flags alone, so every rank
+    # takes the same path (measure() returns a result on rank 0 only).
+    other_name, other_B = None, None
+    if world > 1 and not args.no_extra:
+        if strong:
+            other_name, other_B = "weak", (args.batch or mc0.batch_size)
+        else:
+            gb = REFERENCE_BATCH if args.batch is None else args.batch
+            if gb % world == 0 and ((gb // world) * 64) % 4 == 0:
+                other_name, other_B = "strong", gb // world
+    other_res = None
+    if other_B:
+        other_res = measure(args, args.config, over, other_B, args.T, max(5, args.steps // 2), max(3, args.warmup // 2),
+                            *ctx_args, profile=False)
+
+    extra = extra_other = None
+    if extras_on:
         # the other half of BASELINE.json's metric ("6/12-block"): the canonical 12-block sweep point
-        esteps, ewarm = max(3, args.steps // 3), max(2, min(args.warmup, 3))
-        extra = measure(args, "12block", {}, B, args.T, esteps, ewarm, rank, local_rank, world, dist)
-        if extra is not None:
-            extra["steps"], extra["warmup"] = esteps, ewarm
+        esteps, ewarm = max(5, args.steps // 5), max(2, min(args.warmup, 3))
+        extra = measure(args, "12block", {}, B, args.T, esteps, ewarm, *ctx_args)
+        if other_B:
+            extra_other = measure(args, "12block", {}, other_B, args.T, 5, 2, *ctx_args, profile=False)
 
-    extra4 = None
-    if extra is not None and world == 1 and args.dtype == "fp32":
-        # BASELINE config 4's shape (ImageNet 224/16 preset, its own batch size) on the per-op path: fp32 against the
-        # opt-in bf16 mode, three steps each -- the "bf16 mode >= 2 x fp32" figure, measured by the driver's own run
-        mc4 = __import__("cora_amd").MODEL_CONFIGS["imagenet224"]
-        extra4 = {}
-        for dt in ("fp32", "bf16"):
-            m4 = measure(args, "imagenet224", {}, mc4.batch_size, args.T, 3, 1, rank, local_rank, world, dist, dtype=dt)
-            extra4[dt] = {k: m4[k] for k in ("workload", "value", "ms_per_step", "whole_step_mfma_frac", "kernel_ms_per_inference_step")}
-            extra4[dt].update(steps=3, warmup=1, batch=mc4.batch_size)
-        extra4["bf16_over_fp32"] = extra4["bf16"]["value"] / extra4["fp32"]["value"]
+    single = world == 1 and args.dtype == "fp32" and extras_on
+    extra4 = extra5 = grid = small = None
+    if single:
+        # BASELINE configs 4 and 5 (ImageNet 224/16 preset; 16-frame video, N = 1024) at their own batch sizes:
+        # fp32 against the opt-in bf16 mode, a few steps each, measured by the driver's own run
+        extra4, extra5 = {}, {}
+        for name, dst in (("imagenet224", extra4), ("video16", extra5)):
+            mcx = ca.MODEL_CONFIGS[name]
+            for dt in ("fp32", "bf16"):
+                m = measure(args, name, {}, mcx.batch_size, args.T, 4, 2, *ctx_args, dtype=dt)
+                dst[dt] = brief(m, "kernel_ms_per_inference_step", "roofline", "infer_only_images_steps_per_s")
+                dst[dt]["batch"] = mcx.batch_size
+            dst["bf16_over_fp32"] = dst["bf16"]["value"] / dst["fp32"]["value"]
+        # strong-scaling cost made visible on ONE GPU: the per-GPU batch of an 8 / 4 / 2-GPU run of the reference's
+        # batch of 200 (north_star shards THE batch); 8 x the B=25 figure is the ceiling of that 8-GPU run
+        small = {}
+        for name, full in (("6block", main_res), ("12block", extra)):
+            rows = {}
+            for b in (25, 50, 100):
+                m = measure(args, name, {}, b, args.T, 5, 3, *ctx_args, profile=False)
+                rows[f"B{b}"] = {"value": m["value"], "ms_per_step_median": m["ms_per_step_median"],
+                                 "per_image_rate_vs_B200": m["value"] / full["value"]}
+            rows["strong_scaling_ceiling_8gpu"] = 8.0 * rows["B25"]["value"]
+            rows["strong_scaling_ceiling_4gpu"] = 4.0 * rows["B50"]["value"]
+            rows["strong_scaling_ceiling_2gpu"] = 2.0 * rows["B100"]["value"]
+            small["cfg2" if name == "6block" else "cfg3"] = rows
+    if (args.sweep_grid if args.sweep_grid is not None else single) and world == 1:
+        # BASELINE config 3 is the sweep GRID (sweeps/sweep_12block_comprehensive.yaml:8-47), not only its canonical point
+        grid = {}
+        for D in (64, 96, 128):
+            for H in (1, 2, 4):
+                m = measure(args, "12block", {"hidden_size": D, "num_heads": H}, REFERENCE_BATCH, args.T, 3, 2, *ctx_args)
+                grid[f"D{D}_H{H}"] = {"value": m["value"], "ms_per_step_median": m["ms_per_step_median"],
+                                      "whole_step_mfma_frac": m["whole_step_mfma_frac"], "kernel_path": m["kernel_path"],
+                                      "dominant_kernel": m["roofline"]["kernel"], "dominant_frac": m["roofline"]["frac"]}
 
     if rank == 0:
         r = main_res
         mc, tc = r.pop("mc"), r.pop("tc")
         roof = r.pop("roofline")
         offline_traffic(roof, args.config, B, over)
-        result = {
-            "metric": "PC inference images x T-steps/sec (node)", "value": r["value"], "unit": "images*T-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
-                                         "bf16x3": "f32 as three bf16 terms per GEMM operand / f32 accumulate"}[args.dtype], "data": "synthetic",
-            "config": {"workload": r["workload"], "global_batch": world * B, "T": r["T"],
-                       "parallelism": f"dp{world}" + ("" if world == 1 and r["dp_mode"] == "single" else f" ({r['dp_mode']})"),
-                       "rccl_world_size": (dist.get_world_size() if dist is not None else 1)},
+        scalings = None
+        if world > 1:
+            scalings = {"strong" if strong else "weak": scaling_entry(r, world, "strong" if strong else "weak")}
+            if other_res is not None:
+                scalings[other_name] = scaling_entry(other_res, world, other_name)
+        result = build_line(args, world, r, strong, scalings, dist.get_world_size() if dist is not None else 1)
+        result.update({
             "infer_only_images_steps_per_s": r["infer_only_images_steps_per_s"],
             "algorithmic_flops_per_image_step": r["algorithmic_flops_per_image_step"],
             "whole_step_mfma_frac": r["whole_step_mfma_frac"],
@@ -443,16 +606,19 @@ def main():
             "kernel_ms_per_inference_step": r["kernel_ms_per_inference_step"],
             "hbm_kernels": r["hbm_kernels"],
             "inference_step_kernel_ms_total": r["inference_step_kernel_ms_total"],
-        }
+        })
         if extra is not None:
             extra.pop("mc"); extra.pop("tc")
             offline_traffic(extra["roofline"], "12block", B, {})
-            result["extra"] = {"cfg3": {k: extra[k] for k in (
-                "workload", "value", "ms_per_step", "steps", "warmup", "whole_step_mfma_frac", "roofline",
-                "infer_only_images_steps_per_s", "algorithmic_flops_per_image_step", "kernel_ms_per_inference_step",
-                "dp_mode")}}
-        if extra4 is not None:
-            result["extra"]["cfg4"] = extra4
+            result["extra"] = {"cfg3": brief(extra, "roofline", "infer_only_images_steps_per_s", "algorithmic_flops_per_image_step",
+                                             "kernel_ms_per_inference_step", "dp_mode", "ms_per_step_min", "ms_per_step_max")}
+            if extra_other is not None:
+                result["extra"]["cfg3"]["scalings"] = {
+                    "strong" if strong else "weak": scaling_entry(extra, world, "strong" if strong else "weak"),
+                    other_name: scaling_entry(extra_other, world, other_name)}
+        for key, val in (("cfg4", extra4), ("cfg5", extra5), ("cfg3_grid", grid), ("small_batch", small)):
+            if val is not None:
+                result.setdefault("extra", {})[key] = val
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(mc, tc, B, r["T"])
         else:
@@ -462,6 +628,7 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
+        tick()
         dist.barrier()
         dist.destroy_process_group()
 

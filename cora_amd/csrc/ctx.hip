@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,12 +63,14 @@ const char* rccl_load() {   // nullptr on success, else what failed
 // hipGetSymbolAddress (static_scratch_ptr) and only that pointer is ever handed to kernels.
 #define CORA_STATIC_SCRATCH_FLOATS (4u * 1024u * 1024u)
 static __device__ __align__(256) float scratch[CORA_STATIC_SCRATCH_FLOATS];
-static float* g_scratch_ptr[64] = {};      // per device, filled once with that device current
+static float* g_scratch_ptr[64] = {};      // per device, filled once with that device current (under g_scratch_mu)
+static std::mutex g_scratch_mu;
 // Device address of this GPU's copy of `scratch` (each GPU holds its own copy at its own address).
 // Must run with `device` current and outside stream capture: cora_create does it for its device, and
 // cora_forward_static does it on its first call on a device.
 static int static_scratch_ptr(int device, float** out, std::string* err) {
   if (device < 0 || device >= 64) { *err = "device index out of range"; return -1; }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);   // two host threads may make the first call on a device together
   if (!g_scratch_ptr[device]) {
     float* ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
@@ -155,7 +158,8 @@ struct cora_ctx {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   bool dist_warm = false;
-  bool dist_graph_broken = false;   // a collective could not be captured: cora_step_dist stays on eager launches
+  bool dist_graph_broken = false;   // a collective could not be captured (or cora_dist_set_eager): cora_step_dist stays on eager launches
+  int dist_last_mode = 0;           // how the last cora_step_dist ran: 1 eager, 2 graph replay (cora_dist_mode)
   std::map<int, hipGraphExec_t> dist_graphs;   // key 2 T + exact_clip: T-step loop (+ per-step sum-of-squares all-reduce)
   hipGraphExec_t dist_learn_graph = nullptr;   // wgrad, all-reduce of dE/dW, clip + AdamW, reconstruction
   float apply_graph_scale = 0.f;   // cora_step: weight gradients + AdamW + reconstruction, captured once
@@ -1645,6 +1649,65 @@ static int enqueue_learn_dist(cora_ctx* c) {
   return enqueue_apply(c, 1.0f / ((float)c->B * (float)c->comm_world));
 }
 
+// Replay graphs on this call?  Not before the first (eager) call has run every kernel and collective outside
+// stream capture, not under the profiler, not after a refused capture or cora_dist_set_eager.
+static bool dist_graphs_wanted(cora_ctx* c) {
+  static const bool no_dist_graph = getenv("CORA_DIST_NO_GRAPH") != nullptr;   // operator switch: eager collectives
+  return c->use_graph && !c->prof && c->dist_warm && !c->dist_graph_broken && !no_dist_graph;
+}
+// Build the two graphs of the distributed step if they are missing.  Capturing only records: if RCCL (or HIP)
+// refuses a collective under stream capture on this system, nothing has run, and the step falls back -- for
+// good -- to the eager launch sequence of the first call, which is known to work by then.  The eager sequence
+// issues the same collectives in the same order, so ranks that disagree about graph vs eager still match.
+static bool dist_build_graphs(cora_ctx* c, int T, bool exact) {
+  auto capture = [&](auto&& enqueue, hipGraphExec_t* exec) -> bool {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
+    const int rce = enqueue();
+    const hipError_t e = hipStreamEndCapture(c->st, &graph);
+    bool ok = (rce == 0 && e == hipSuccess && graph != nullptr);
+    if (ok) ok = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) hipGraphDestroy(graph);
+    if (!ok) (void)hipGetLastError();
+    return ok;
+  };
+  const int key = 2 * T + (exact ? 1 : 0);
+  bool ok = true;
+  if (c->dist_graphs.find(key) == c->dist_graphs.end()) {
+    hipGraphExec_t exec = nullptr;
+    if (capture([&]() { return enqueue_infer_dist(c, T, exact); }, &exec)) c->dist_graphs[key] = exec;
+    else ok = false;
+  }
+  if (ok && !c->dist_learn_graph && !capture([&]() { return enqueue_learn_dist(c); }, &c->dist_learn_graph)) {
+    c->dist_learn_graph = nullptr;
+    ok = false;
+  }
+  if (!ok) c->dist_graph_broken = true;
+  return ok;
+}
+
+// Capture (not launch) the graphs cora_step_dist(T, exact_clip) would replay: 0 = ready, 1 = this system refuses
+// a collective under capture (the ctx stays on eager launches), < 0 error.  Lets the host agree on graph vs eager
+// across ranks BEFORE the first replay (cora_amd/dist.py: DataParallel.agree_on_graphs).
+int cora_dist_prepare(cora_ctx* c, int T, int exact_clip) {
+  if (!c) return -1;
+  if (!c->comm) FAIL(-1, "cora_dist_prepare: call cora_comm_init first");
+  if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
+  if (!c->dist_warm) FAIL(-1, "cora_dist_prepare: run one cora_step_dist first (RCCL sets its channels up on first use)");
+  HCHECK(hipSetDevice(c->device));
+  if (int rc_ = settle_pending(c)) return rc_;
+  if (!dist_graphs_wanted(c)) return 1;
+  return dist_build_graphs(c, T, exact_clip != 0) ? 0 : 1;
+}
+int cora_dist_set_eager(cora_ctx* c, int eager) {
+  if (!c) return -1;
+  c->dist_graph_broken = eager != 0;
+  return 0;
+}
+// How the LAST cora_step_dist ran: 0 = none yet / no communicator, 1 = eager launches (first call, CORA_NO_GRAPH,
+// refused capture or cora_dist_set_eager), 2 = two graph replays with the collectives as graph nodes.
+int cora_dist_mode(const cora_ctx* c) { return c ? c->dist_last_mode : -1; }
+
 int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, float eta_w,
                    int exact_clip, cora_step_out* out) {
   if (!c) return -1;
@@ -1667,38 +1730,11 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
   HCHECK(hipMemcpyAsync(c->eta_dev, c->host_in, sizeof(float) * T, hipMemcpyHostToDevice, c->st));
   HCHECK(hipMemcpyAsync(c->hyp_dev, hy, sizeof(float) * 4, hipMemcpyHostToDevice, c->st));
   c->last_T = T;
-  static const bool no_dist_graph = getenv("CORA_DIST_NO_GRAPH") != nullptr;   // operator switch: eager collectives
-  bool graphed = c->use_graph && !c->prof && c->dist_warm && !c->dist_graph_broken && !no_dist_graph;
+  bool graphed = dist_graphs_wanted(c);
   hipGraphExec_t infer_exec = nullptr;
   if (graphed) {
-    // Build the two graphs if they are missing.  Capturing only records: if RCCL (or HIP) refuses a
-    // collective under stream capture on this system, nothing has run, every rank sees the same refusal
-    // at the same call, and the step falls back -- for good -- to the eager launch sequence of the
-    // first call, which is known to work by then.
-    auto capture = [&](auto&& enqueue, hipGraphExec_t* exec) -> bool {
-      hipGraph_t graph = nullptr;
-      if (hipStreamBeginCapture(c->st, hipStreamCaptureModeRelaxed) != hipSuccess) return false;
-      const int rce = enqueue();
-      const hipError_t e = hipStreamEndCapture(c->st, &graph);
-      bool ok = (rce == 0 && e == hipSuccess && graph != nullptr);
-      if (ok) ok = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0) == hipSuccess;
-      if (graph) hipGraphDestroy(graph);
-      if (!ok) (void)hipGetLastError();
-      return ok;
-    };
-    const int key = 2 * T + (exact ? 1 : 0);
-    auto it = c->dist_graphs.find(key);
-    if (it == c->dist_graphs.end()) {
-      hipGraphExec_t exec = nullptr;
-      if (capture([&]() { return enqueue_infer_dist(c, T, exact); }, &exec)) { c->dist_graphs[key] = exec; it = c->dist_graphs.find(key); }
-      else graphed = false;
-    }
-    if (graphed && !c->dist_learn_graph && !capture([&]() { return enqueue_learn_dist(c); }, &c->dist_learn_graph)) {
-      c->dist_learn_graph = nullptr;
-      graphed = false;
-    }
-    if (graphed) infer_exec = it->second;
-    else c->dist_graph_broken = true;
+    if (dist_build_graphs(c, T, exact)) infer_exec = c->dist_graphs[2 * T + (exact ? 1 : 0)];
+    else graphed = false;
   }
   if (!graphed) {
     // first call (and CORA_NO_GRAPH, and after a refused capture): eager launches -- every kernel and
@@ -1713,6 +1749,7 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
     HCHECK(hipEventRecord(c->ev1, c->st));
     HCHECK(hipGraphLaunch(c->dist_learn_graph, c->st));
   }
+  c->dist_last_mode = graphed ? 2 : 1;
   c->adam_count += 1;
   HCHECK(hipEventRecord(c->ev2, c->st));
   double* ho = c->host_out;

@@ -597,7 +597,8 @@ static int launch_wide_t(const FusedP& p, int L, hipStream_t st) {
 }
 
 bool fused_wide_supported(int N, int P, int D, int H, int M) {
-  if (N != 64 || M != 4 * D || P % 4) return false;
+  // P == 48: the edge layers (edge_path_wide, fused_wide_common.h) hard-code the 4x4x3 patch of the sweep configs
+  if (N != 64 || M != 4 * D || P != 48) return false;
   if (D == 128) return H == 1 || H == 2 || H == 4;
   if (D == 96) return H == 1 || H == 2 || H == 4;
   return false;

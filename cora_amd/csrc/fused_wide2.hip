@@ -702,7 +702,8 @@ __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
 }
 
 size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
-bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && H == 4 && M == 4 * D && P % 4 == 0; }
+// P == 48: the edge layers (edge_path_wide, fused_wide_common.h) are written for the 4x4x3 patch of the sweep configs
+bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && H == 4 && M == 4 * D && P == 48; }
 
 int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
   static bool attr[64] = {};

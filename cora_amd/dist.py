@@ -84,11 +84,49 @@ class DataParallel:
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             _lib.check(lib.cora_comm_init(ctx, ident[0], 128, rank, world), ctx)
             self.buf = None
+            self._agreed_T = set()
             return
         dev = torch.device("cuda", model.device)
         self.buf = torch.zeros(model._nW, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
         _lib.check(_lib.load().cora_bind_wgrad_buffer(ctx, C.c_void_p(self.buf.data_ptr()), self.buf.numel()), ctx)
+
+    def agree_on_graphs(self, model, T: int) -> str:
+        """In-library RCCL step: after the first (eager) cora_step_dist, every rank captures -- without
+        launching -- the graphs the next call would replay (cora_dist_prepare) and the ranks agree over the
+        torch group: graph replay only if EVERY rank could capture, eager collectives everywhere otherwise.
+        The decision is taken before any replay, over a transport that is independent of the captured
+        collectives, so no rank can sit in a graphed all-reduce waiting for one that fell back.
+        Returns "graph" or "eager"; a no-op after the first call for a given T."""
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        if not self.in_library:
+            return "n/a"
+        lib, ctx = _lib.load(), model._ctx
+        if T in self._agreed_T:
+            return "graph" if lib.cora_dist_mode(ctx) != 1 else "eager"
+        rc = lib.cora_dist_prepare(ctx, T, int(self.exact_clip))
+        if rc < 0:
+            _lib.check(rc, ctx)
+        ready = 1 if rc == 0 else 0
+        if self.world > 1 and dist.is_initialized():
+            on_gpu = dist.get_backend(self.group) != "gloo"
+            flag = torch.tensor([ready], dtype=torch.int32, device=torch.device("cuda", model.device) if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ready = int(flag.item())
+        if not ready:
+            _lib.check(lib.cora_dist_set_eager(ctx, 1), ctx)
+        self._agreed_T.add(T)
+        return "graph" if ready else "eager"
+
+    def step_mode(self, model) -> str:
+        """How the last in-library step ran: "graph" (collectives replayed as graph nodes) or "eager"."""
+        from . import _lib
+        if not self.in_library:
+            return "split"
+        return {1: "eager", 2: "graph"}.get(_lib.load().cora_dist_mode(model._ctx), "none")
 
     def allreduce(self) -> int:
         # cora_wgrad synchronised its stream before returning, so the buffer is complete here.

@@ -488,7 +488,8 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
     model._grad_options(not model.config.update_weights_every_inference_step)
     if model.config.update_weights_every_inference_step:      # MODE 1 (iPC), reference :418-439
         if model._dp is not None:
-            raise NotImplementedError("iPC mode is single-GPU (one all-reduce per inference step is not built)")
+            raise NotImplementedError("iPC mode is single-GPU (one dE/dW all-reduce per inference step is not built; "
+                                      "DESIGN.md section 5)")
         eta_ws = np.array([lr_at(rw.base.learning_rate, optim_w.count + t) for t in range(T)], dtype=np.float32)
         _lib.check(lib.cora_step_ipc(ctx, _fptr(x), 0, T, _fptr(eta_h), _fptr(eta_ws), C.byref(out)), ctx)
         optim_w.count += T - 1                               # the common `count += 1` below makes it T
@@ -497,6 +498,7 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
     elif model._dp.in_library:                                # RCCL inside the captured graphs
         _lib.check(lib.cora_step_dist(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w),
                                       int(model._dp.exact_clip), C.byref(out)), ctx)
+        model._dp.agree_on_graphs(model, T)                   # once per T, after the first (eager) call
     else:
         if model._dp.exact_clip:
             model._dp.infer_exact(model, ctx, x, T, eta_h, out)

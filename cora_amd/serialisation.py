@@ -6,8 +6,9 @@ Same file format as /root/reference/pcx/utils/_serialisation.py:25-105: one
 ".vodes[0].h", ...), so checkpoints written by the reference driver
 (examples/debug_transformer_wandb.py:1278) load here and vice versa.
 `filter` accepts the same spellings: a class or union of classes out of LayerParam / VodeParam, or a
-predicate on a parameter object (the reference's `Callable[[Any], bool]`, :28,41-45), which is asked
-once per parameter family with one of that family's proxies.
+predicate on a parameter object (the reference's `Callable[[Any], bool]`, :28,41-45), which -- as in the
+reference, :41-53 -- is asked for EVERY parameter (each LayerParam proxy, each vode's h), so a predicate
+may select inside a family (some blocks only, only vodes whose h is set, ...).
 """
 from __future__ import annotations
 
@@ -32,37 +33,41 @@ def _wants(filter, cls, sample=None) -> bool:
     raise TypeError("filter must be LayerParam, VodeParam, a union of them or a predicate")
 
 
-def _samples(model):
-    return model.vodes[0].h, model.patch_projection.nn.weight
+def _layer_params(model):
+    """key -> LayerParam proxy for every weight of the model, in checkpoint order."""
+    return {k: LayerParam(model, k, model._shapes[k]) for k in model.param_keys()}
 
 
 def save_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
     data: Dict[str, np.ndarray] = {}
-    sv, sl = _samples(model)
-    if _wants(filter, VodeParam, sv):
-        for l in range(model.L + 3):
+    for l in range(model.L + 3):
+        if _wants(filter, VodeParam, model.vodes[l].h):
             v = model.vodes[l].h.get()
             if v is not None:
                 data[vode_key(l)] = v
-    if _wants(filter, LayerParam, sl):
-        data.update(model.get_weights())
+    chosen = [k for k, prox in _layer_params(model).items() if _wants(filter, LayerParam, prox)]
+    if chosen:
+        weights = model.get_weights()             # one device read for the whole arena
+        data.update({k: weights[k] for k in chosen})
     np.savez_compressed(path, **data)
 
 
 def load_params(model: TransformerDecoder, path: str, filter=LayerParam) -> None:
     path = path if path.endswith(".npz") else f"{path}.npz"
-    sv, sl = _samples(model)
     with np.load(path) as loaded:          # allow_pickle stays False
-        if _wants(filter, LayerParam, sl):
-            weights = {}
-            for key in model.param_keys():
-                if key not in loaded:
-                    raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
-                weights[key] = loaded[key]
+        weights = {}
+        for key, prox in _layer_params(model).items():
+            if not _wants(filter, LayerParam, prox):
+                continue
+            if key not in loaded:
+                raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
+            weights[key] = loaded[key]
+        if weights:
             model.set_weights(weights)
-        if _wants(filter, VodeParam, sv):
-            for l in range(model.L + 3):
-                key = vode_key(l)
-                if key not in loaded:
-                    raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
-                model.vodes[l].h.set(loaded[key])
+        for l in range(model.L + 3):
+            if not _wants(filter, VodeParam, model.vodes[l].h):
+                continue
+            key = vode_key(l)
+            if key not in loaded:
+                raise KeyError(f"Parameter '{key}' not found in the file '{path}'.")
+            model.vodes[l].h.set(loaded[key])

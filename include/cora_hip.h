@@ -187,6 +187,19 @@ int cora_comm_init(cora_ctx* ctx, const void* id128, size_t nbytes, int rank, in
 int cora_comm_info(const cora_ctx* ctx, int* rank, int* world);   /* rank -1 / world 0: no communicator */
 int cora_step_dist(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h, float eta_w,
                    int exact_clip, cora_step_out* out);
+/* Graph vs eager collectives, agreed across ranks before the first replay (no counterpart in the reference,
+ * which is single-device; its jit compiles one executable per (config, T, B), src/decoder_transformer.py:392).
+ * After the first cora_step_dist (which always runs eagerly), cora_dist_prepare CAPTURES -- does not launch --
+ * the two graphs the next call with this (T, exact_clip) would replay: 0 = ready, 1 = a collective was refused
+ * under stream capture on this system (the ctx then stays on eager launches, which issue the same collectives
+ * in the same order), < 0 error.  The host all-reduces MIN of "ready" over its own process group and, unless
+ * every rank is ready, calls cora_dist_set_eager(ctx, 1) on all of them, so a run is either graph replay
+ * everywhere or eager everywhere (cora_amd/dist.py: DataParallel.agree_on_graphs).  cora_dist_mode reports how
+ * the LAST cora_step_dist ran: 0 none yet, 1 eager launches, 2 graph replay -- bench.py prints it, so an eager
+ * number cannot pass for a graphed one. */
+int cora_dist_prepare(cora_ctx* ctx, int T, int exact_clip);
+int cora_dist_set_eager(cora_ctx* ctx, int eager);
+int cora_dist_mode(const cora_ctx* ctx);
 
 /* Device pointer + length of the flat dE/dW buffer (same layout as the weight arena). */
 int cora_wgrad_buffer(cora_ctx* ctx, void** dev_ptr, size_t* n_floats);
@@ -206,12 +219,13 @@ int cora_forward(cora_ctx* ctx, float* xhat_host, size_t n_floats);
  *   pos_dev [N, D], h0_dev [B, N, P]  ->  xhat_dev [B, C, H, W]   (all device pointers, caller-owned)
  * Every intermediate lives in a 16 MiB static __device__ array of the library (one copy per GPU, held
  * until the process ends); cora_forward_static_floats(cfg) says how much of it a configuration needs and
- * the call fails with a clear error above 4 Mi floats (cfg 2 shape: B <= 73).  Only kernel launches on
+ * the call fails with a clear error above 4 Mi floats (cfg 2 shape: 56 640 floats per image, B <= 74).  Only kernel launches on
  * `hip_stream` (a hipStream_t, NULL = the null stream): no hipMalloc / hipFree, no copies, no
  * synchronisation.  The FIRST call on a device resolves the array's address (hipGetSymbolAddress) and so
  * must not sit inside a stream capture unless a cora_create on that device came first.  All calls on one
  * GPU share that GPU's array (it keeps the last call's contents; nothing in this path needs it zeroed):
- * calls that overlap on one GPU race.  Errors: cora_last_error(NULL). */
+ * calls that overlap on one GPU race.  Host side: thread-safe (the per-device address is resolved under a lock,
+ * the error string is per thread).  Errors: cora_last_error(NULL). */
 size_t cora_forward_static_floats(const cora_config* cfg);
 int cora_forward_static(const cora_config* cfg, int device, const float* W_dev, size_t n_weights,
                         const float* pos_dev, const float* h0_dev, float* xhat_dev, void* hip_stream);

@@ -38,13 +38,15 @@ FULL_CASES = {
     "cfg3_12block_D128_H4_B32_T20": ("12block", {}, 32, 20),
     "cfg3_12block_D96_H4_B16_T20": ("12block", {"hidden_size": 96}, 16, 20),
     "cfg5_video16_N1024_L2_B1_T20": ("video16", {"num_blocks": 2}, 1, 20),
+    "cfg5_video16_N1024_L6_B1_T20": ("video16", {}, 1, 20),          # config 5 at its own depth
     "cfg4_imagenet224_L6_B2_T10": ("imagenet224", {}, 2, 10),
 }
 
 
 # the same cases in the opt-in bf16 mode (bar 1e-2): the shapes its bf16 GEMM + bf16 attention kernels serve,
 # with all T chained steps (the 64-token configs run their fused fp32 kernels only in fp32 mode)
-BF16_FULL_CASES = ["cfg4_imagenet224_L6_B2_T10", "cfg5_video16_N1024_L2_B1_T20", "cfg3_12block_D128_H4_B32_T20"]
+BF16_FULL_CASES = ["cfg4_imagenet224_L6_B2_T10", "cfg5_video16_N1024_L2_B1_T20", "cfg5_video16_N1024_L6_B1_T20",
+                   "cfg3_12block_D128_H4_B32_T20"]
 BF16_TOL = 1e-2
 # dtype_mode 2 (three-term bf16 split in the per-op GEMMs, fp32-grade products) at full size, held to the fp32 bars
 BF16X3_FULL_CASES = ["cfg2_6block_B200_T20", "cfg3_12block_D128_H4_B32_T20", "cfg4_imagenet224_L6_B2_T10"]

@@ -95,7 +95,45 @@ def test_bench_self_launch_two_ranks_cpu():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["world_observed"] == 2 and r["max_over_ranks"] == 2.0
     assert r["scaling"] == "strong" and r["per_gpu_batch"] == 100 and r["global_batch"] == 200
+    # the N > 1 line carries BOTH scalings (built by the same build_line / scaling_entry as the measured line): the
+    # config's batch on every GPU (weak) and the reference's batch of 200 sharded over the ranks (strong), each with
+    # its own global batch, and a parallelism string that names the data-parallel mode
+    assert set(r["scalings"]) == {"weak", "strong"}
+    wk, st = r["scalings"]["weak"], r["scalings"]["strong"]
+    assert wk["scaling"] == "weak" and wk["config"]["global_batch"] == 400 and wk["config"]["per_gpu_batch"] == 200
+    assert st["scaling"] == "strong" and st["config"]["global_batch"] == 200 and st["config"]["per_gpu_batch"] == 100
+    assert r["config"]["global_batch"] == 200 and r["config"]["parallelism"].startswith("dp2 (")
+    for e in (wk, st):
+        assert {"value", "ms_per_step", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max"} <= set(e)
+        assert e["config"]["parallelism"].startswith("dp2 (")
+    assert {"ms_per_step_median", "ms_per_step_min", "ms_per_step_max", "value_from_mean", "timing"} <= set(r)
     # a rank that fails takes the launcher down with a non-zero exit (no hang)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch",
                         "--global-batch", "7"], env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0      # dry run does not validate divisibility: both ranks report and exit cleanly
+
+
+def test_bench_line_names_graph_or_eager_collectives():
+    """bench.build_line / scaling_entry (pure functions): the parallelism string of an N > 1 line carries the
+    data-parallel mode bench.measure composed -- backend, clip mode and whether cora_step_dist REPLAYED graphs or
+    launched its collectives eagerly (cora_dist_mode) -- so an eager number cannot pass for a graphed one."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse_args(["--gpus", "8"])
+    assert args.steps >= 50 and args.warmup >= 10          # SURVEY 8(d) protocol defaults
+
+    def res(b, mode):
+        return {"value": 1.0, "value_from_mean": 1.0, "ms_per_step": 1.0, "ms_per_step_median": 1.0, "ms_per_step_min": 1.0,
+                "ms_per_step_max": 1.0, "steps": 50, "warmup": 10, "workload": "w", "per_gpu_batch": b, "T": 20,
+                "dp_mode": mode, "whole_step_mfma_frac": 0.5}
+    sc = {"weak": bench.scaling_entry(res(200, "rccl:exact-clip:graph"), 8, "weak"),
+          "strong": bench.scaling_entry(res(25, "rccl:exact-clip:eager"), 8, "strong")}
+    line = bench.build_line(args, 8, res(200, "rccl:exact-clip:graph"), False, sc, 8)
+    assert line["scaling"] == "weak" and line["config"]["global_batch"] == 1600
+    assert line["config"]["parallelism"] == "dp8 (rccl:exact-clip:graph)"
+    assert line["scalings"]["strong"]["config"]["parallelism"] == "dp8 (rccl:exact-clip:eager)"
+    assert line["scalings"]["strong"]["config"]["global_batch"] == 200
+    assert bench.parallelism_name(1, "single") == "dp1"

@@ -163,13 +163,29 @@ def test_in_library_rccl_world1_matches_single_gpu_step(name, exact):
             r, w = C.c_int(), C.c_int()
             _lib.check(_lib.load().cora_comm_info(model._ctx, C.byref(r), C.byref(w)), model._ctx)
             assert dp.in_library and (r.value, w.value) == (0, 1)
-        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(4)]
+        outs, modes = [], []
+        for _ in range(4):
+            outs.append(ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh))
+            if dist_path:
+                modes.append(dp.step_mode(model))
+        if dist_path:
+            # cora_dist_mode: the first call launches eagerly (RCCL warm-up), then -- the ranks having agreed through
+            # cora_dist_prepare / DataParallel.agree_on_graphs -- every later call replays the captured graphs
+            assert modes == ["eager", "graph", "graph", "graph"], modes
+            assert dp.agree_on_graphs(model, T) == "graph"
+            # an operator (or a rank that could not capture) can pin every rank to eager collectives
+            _lib.check(_lib.load().cora_dist_set_eager(model._ctx, 1), model._ctx)
+            outs.append(ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh))
+            assert dp.step_mode(model) == "eager"
+            _lib.check(_lib.load().cora_dist_set_eager(model._ctx, 0), model._ctx)
+        else:
+            outs.append(ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh))
         tot, per = ca.step_energies(model, T)
         res.append((outs, [model.vodes[l].h.get() for l in range(len(case["h"]))], model.get_weights(), tot,
                     model.get_adam_state()[2]))
         model.close()
     (a, ha, wa, ea, ca_), (b, hb, wb, eb, cb_) = res
-    assert ca_ == cb_ == 4
+    assert ca_ == cb_ == 5
     # same kernels on the same inputs; the only run-to-run freedom is the order of float atomics in the
     # split-K weight gradients and the slotted energy sums
     for oa, ob in zip(a, b):

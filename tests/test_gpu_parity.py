@@ -38,6 +38,13 @@ CASES = {
     "d64_h2_fused": ((3, 32, 32), 4, 64, 2, 3, 3, 4),      # fused kernel, head dim 32
     "d64_h4_fused_12block": ((3, 32, 32), 4, 64, 4, 12, 2, 3),   # fused kernel, head dim 16 (a 12-block sweep point)
     "cfg3_shape_B2": ((3, 32, 32), 4, 128, 4, 12, 2, 3),
+    # pc_block_wide2_kernel at a depth where no fp32 floor relaxes a bar: its VJP held to the plain 1e-4 on every gh
+    "d128_h4_shallow": ((3, 32, 32), 4, 128, 4, 2, 2, 3),
+    "d128_h1_shallow": ((3, 32, 32), 4, 128, 1, 2, 2, 3),      # pc_block_wide_kernel (one workgroup per CU form), head dim 128
+    # N = 64 and D = 96 / 128 but a patch dim other than 48: the wide fused kernels' edge layers are written for
+    # P = 48, so these must take the per-op path (asserted in test_wide_kernels_need_patch_dim_48)
+    "d128_h4_P16": ((1, 32, 32), 4, 128, 4, 2, 2, 3),
+    "d96_h2_P192": ((3, 64, 64), 8, 96, 2, 2, 2, 3),
     "n36_h2_ragged_chunk": ((3, 24, 24), 4, 32, 2, 2, 2, 3),   # N = 36: masked rows in the single-chunk attention kernels
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
@@ -50,11 +57,13 @@ CASES = {
 }
 
 
-def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=False, compute_dtype="fp32", **kw):
+def run_case(name, l1=0.0, l2=0.0, clip_h=2000.0, clip_w=500.0, return_floor=False, compute_dtype="fp32", expect_path=None, **kw):
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
     case = make_case(shape, p, D, H, L, B, seed=zlib.crc32(name.encode()) % 1000, l1=l1, l2=l2, clip_h=clip_h, clip_w=clip_w, **kw)
     model, optim_w, optim_h = build_model(case, compute_dtype=compute_dtype)
+    if expect_path is not None:
+        assert model.kernel_path() == expect_path, (name, model.kernel_path())
     eta = [0.095] * T
     args = (T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], eta, 1e-3)
     ref = R.train_on_batch(*args)
@@ -110,6 +119,15 @@ def bar_for(key, floor):
 @pytest.mark.parametrize("name", list(CASES))
 def test_step_parity(name):
     run_case(name)
+
+
+@pytest.mark.parametrize("name,path", [("d128_h4_P16", "per-op"), ("d96_h2_P192", "per-op"), ("d128_h4_shallow", "fused-wide"),
+                                       ("d128_h1_shallow", "fused-wide"), ("cfg2_shape_B4", "fused")])
+def test_wide_kernels_need_patch_dim_48(name, path):
+    """cora_kernel_path: the wide fused kernels (D = 96 / 128) take P = 48 only -- their edge layers hard-code the
+    4x4x3 patch (fused_wide_common.h: edge_path_wide) -- so a 64-token config with another patch dim (a 1-channel
+    32x32 image: P = 16; 64x64 with 8x8 patches: P = 192) runs the per-op path, and passes the same bars there."""
+    run_case(name, expect_path=path)
 
 
 def test_regularisers_and_clipping():

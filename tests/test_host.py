@@ -225,6 +225,17 @@ def test_npz_layer_param_keys_and_round_trip(tmp_path, vode_ln):
     ca.save_params(m2, str(tmp_path / "pred"), filter=lambda p: isinstance(p, ca.LayerParam))
     with np.load(str(tmp_path / "pred.npz")) as z:
         assert set(z.files) == want
+    # the predicate is asked per parameter (reference :41-53), so it can select INSIDE a family: block 1 only
+    only_b1 = lambda p: isinstance(p, ca.LayerParam) and p.key.startswith(".transformer_blocks[1]")
+    ca.save_params(m2, str(tmp_path / "b1"), filter=only_b1)
+    with np.load(str(tmp_path / "b1.npz")) as z:
+        assert set(z.files) == {k for k in want if k.startswith(".transformer_blocks[1]")}
+    m3 = ca.TransformerDecoder(cfg, seed=5)
+    before = m3.get_weights()
+    ca.load_params(m3, str(tmp_path / "b1"), filter=only_b1)       # loads block 1, leaves everything else alone
+    after = m3.get_weights()
+    for k in want:
+        np.testing.assert_array_equal(after[k], blob[k] if k.startswith(".transformer_blocks[1]") else before[k])
     del blob[".output_projection.nn.bias"]
     np.savez_compressed(str(tmp_path / "short"), **blob)
     with pytest.raises(KeyError, match="not found in the file"):

@@ -69,6 +69,12 @@ def test_forward_static_rejects_oversize_and_bad_args():
     pt = C.c_void_p(dummy.data_ptr())
     rc = lib.cora_forward_static(C.byref(cfg), 0, pt, model._nW, pt, pt, pt, None)
     assert rc != 0 and b"scratch" in lib.cora_last_error(None)
+    # the documented limit at the cfg-2 shape: 56 640 floats per image -> B = 74 fits the 4 Mi floats, B = 75 does not
+    c74, c75 = model._make_cfg(74), model._make_cfg(75)
+    assert lib.cora_forward_static_floats(C.byref(c74)) == 74 * 56640 <= 4 * 1024 * 1024
+    assert lib.cora_forward_static_floats(C.byref(c75)) > 4 * 1024 * 1024
+    rc = lib.cora_forward_static(C.byref(c75), 0, pt, model._nW, pt, pt, pt, None)
+    assert rc != 0 and b"scratch" in lib.cora_last_error(None)
     cfg = model._make_cfg(4)
     assert lib.cora_forward_static_floats(C.byref(cfg)) < 4 * 1024 * 1024
     rc = lib.cora_forward_static(C.byref(cfg), 0, pt, model._nW + 1, pt, pt, pt, None)
