@@ -249,6 +249,30 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st);
 int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st);
 // the same for every shape fused_wide_supported() takes (one workgroup per CU form)
 int launch_chain_wide(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st);
+// ---- row-tile fused kernels (fused_rows.hip): D = 64, M = 256, any sequence length ---------------------------
+// One workgroup per 64-row tile of one block; attention (attn.hip) runs between rows_qkv / rows_mid / rows_out.
+struct RowsP {
+  const float* X;        // vodes 1..L+1, [L+1][rows][64]: block g reads X + g nl and predicts X + (g + 1) nl
+  float* E2;             // errors of vodes 2..L+1: e_{g+2} -> E2 + g nl
+  const float* E1;       // errors of vodes 1..L (own error of the vode block g reads): E1 + g nl
+  float* G1;             // gradients of vodes 1..L: g_{g+1} -> G1 + g nl
+  const float* W; const float* WT;
+  long long oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, tWqkv, tWo, tW1, tW2;
+  float* qkv; const float* att; float* dO; float* rdy; const float* dqkv;   // [L rows, 3D | D | D | D | 3D]
+  long long rows;        // B * N token rows per block (multiple of 64)
+  int L;
+  double* energy;        // energy[g] += energy of vode g + 2
+  double* sumsq;         // sumsq[g * 8 + slot] += |g_{g+1}|^2
+  const float* gscale; float l1, l2;
+  // store pass (learning phase): operands of the weight-gradient contractions + per-wave column sums
+  float *S_xn1, *S_xn2, *S_a, *S_da, *S_dy, *colpart;
+};
+bool fused_rows_supported(long long rows, int D, int M);
+size_t fused_rows_colpart_floats(int L, long long rows);
+int launch_rows_qkv(const RowsP& p, int store, hipStream_t st);
+int launch_rows_mid(const RowsP& p, int store, hipStream_t st);
+int launch_rows_out(const RowsP& p, int store, hipStream_t st);
+void launch_rows_colpart_reduce(const RowsP& p, float* dW, hipStream_t st);   // after the three store launches
 void launch_colpart_reduce(const FusedP& p, int L, hipStream_t st);   // after a MODE_STORE launch
 size_t fused_colpart_floats(int L, int B);
 void launch_transpose(const float* src, float* dst, int rows, int cols, int groups, hipStream_t st);

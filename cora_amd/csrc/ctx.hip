@@ -22,9 +22,9 @@ namespace {
 
 thread_local std::string g_create_err;
 
-enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_FUSED, K_GRADFIN, K_COUNT };
+enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD, K_UPDATE, K_OTHER, K_FUSED, K_GRADFIN, K_ROWS, K_COUNT };
 const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd",
-                                   "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "vode_grad"};
+                                   "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "vode_grad", "pc_rows_fused"};
 
 struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
 
@@ -119,6 +119,7 @@ struct cora_ctx {
   bool fused = false;     // D = 64 fused kernel (inference, STORE and chain modes)
   bool fusedw = false;    // D = 96 / 128 fused kernel (inference step only; learning phase and chain stay per-op)
   bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
+  bool frows = false;     // D = 64 at any sequence length: row-tile fused kernels around attn.hip (fused_rows.hip)
   bool slotted() const { return fused || fusedw; }   // inference-step energies kept as 8 partial sums per vode (esum)
 
   // vodes
@@ -493,6 +494,45 @@ void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */
   f.dbg = c->dbg;
 }
 
+// parameter block of the row-tile fused kernels (fused_rows.hip)
+void fill_rows(cora_ctx* c, RowsP& r, double* en2 /* energy of vode 2 */, double* ss1 /* sumsq slots of vode 1 */) {
+  memset(&r, 0, sizeof r);
+  r.X = vode_ptr(c, c->Hs, 1); r.E2 = err_ptr(c, 2); r.E1 = err_ptr(c, 1); r.G1 = vode_ptr(c, c->Gs, 1);
+  r.W = c->W; r.WT = c->WT;
+  r.oLn1g = c->oLn1g; r.oLn1b = c->oLn1b; r.oLn2g = c->oLn2g; r.oLn2b = c->oLn2b; r.oWqkv = c->oWqkv; r.oWo = c->oWo;
+  r.oW1 = c->oW1; r.ob1 = c->ob1; r.oW2 = c->oW2; r.ob2 = c->ob2;
+  r.tWqkv = c->tWqkv; r.tWo = c->tWo; r.tW1 = c->tW1; r.tW2 = c->tW2;
+  r.qkv = c->qkv; r.att = c->att; r.dO = c->dO; r.rdy = c->dzn; r.dqkv = c->dqkv;
+  r.rows = c->BN; r.L = c->L; r.energy = en2; r.sumsq = ss1; r.gscale = c->gscale; r.l1 = c->cfg.l1; r.l2 = c->cfg.l2;
+  r.S_xn1 = c->xn1; r.S_xn2 = c->xn2; r.S_a = c->a; r.S_da = c->da; r.S_dy = c->dy; r.colpart = c->colpart;
+}
+// Row-tile path, forward half of all L blocks: q|k|v, attention, then e_{2..L+1}, their energies, dO and r + dy.
+// store: also leave the operands of the weight-gradient contractions (learning phase).
+int block_forward_rows(cora_ctx* c, double* en2, int store) {
+  const int L = c->L, D = c->D;
+  const double rows = (double)L * c->BN;
+  RowsP r; fill_rows(c, r, en2, nullptr);
+  { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 4 * D);
+    if (launch_rows_qkv(r, store, c->st)) FAIL(-3, "rows_qkv: launch set-up failed"); }
+  { KScope s(c, K_ATTN_FWD, 4.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 4 * D);
+    if (launch_attn_fwd(c->qkv, c->att, c->lse, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention: head dim not supported"); }
+  { KScope s(c, K_ROWS, rows * (4.0 * D * D + 8.0 * D * c->M), 4.0 * rows * 6 * D);
+    if (launch_rows_mid(r, store, c->st)) FAIL(-3, "rows_mid: launch set-up failed"); }
+  return 0;
+}
+// ... and the backward half: attention backward, then the vode gradients g_1..g_L with their sums of squares
+// (store: the LayerNorm-1 column sums instead)
+int block_backward_rows(cora_ctx* c, double* ss1, int store) {
+  const int L = c->L, D = c->D;
+  const double rows = (double)L * c->BN;
+  RowsP r; fill_rows(c, r, nullptr, ss1);
+  { KScope s(c, K_ATTN_BWD, 14.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 9 * D);
+    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward: head dim not supported"); }
+  { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 7 * D);
+    if (launch_rows_out(r, store, c->st)) FAIL(-3, "rows_out: launch set-up failed"); }
+  return 0;
+}
+
 // energy + errors at the current vodes into slot `slot` of the energy log (status None forward)
 // vodes 1..L+1 through their LayerNorms (use_vode_state_layernorm, :232-241): hln = LN_v(h_v)
 void vode_ln_forward(cora_ctx* c) {
@@ -503,13 +543,14 @@ void vode_ln_forward(cora_ctx* c) {
 // what block g / the output projection read: the vode itself, or its normalised copy
 const float* vode_in(cora_ctx* c, int l) { return c->vln ? c->hln + (long long)(l - 1) * c->nl : vode_ptr(c, c->Hs, l); }
 
-int errors_pass(cora_ctx* c, int slot) {
+int errors_pass(cora_ctx* c, int slot, int store = 0) {
   const int L = c->L;
   double* en = c->energies + (long long)slot * (L + 3);
   if (c->vln) vode_ln_forward(c);
   patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
   if (L > 0) {
-    int rc = block_forward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
+    int rc = c->frows ? block_forward_rows(c, en + 2, store)
+                      : block_forward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
     if (rc) return rc;
   }
   out_proj(c, vode_in(c, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
@@ -582,7 +623,8 @@ int infer_grad_step(cora_ctx* c, int t) {
   }
   run_gemm(c, p, false, bko_out);
   if (L > 0) {
-    if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true);
+    if (c->frows) rc = block_backward_rows(c, ss + 8, 0);
+    else if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true);
     else rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
     if (rc) return rc;
   }
@@ -817,7 +859,9 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->fusedw = (!c->fused && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_wide_supported(c->N, c->P, c->D, c->H, c->M) &&
                getenv("CORA_NO_FUSED") == nullptr);
   c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
-  if (c->fused || c->fusedw || cfg->dtype_mode != 0) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
+  c->frows = (!c->fused && !c->fusedw && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_rows_supported(c->BN, c->D, c->M) &&
+              getenv("CORA_NO_FUSED") == nullptr && getenv("CORA_NO_ROWS") == nullptr);
+  if (c->fused || c->fusedw || c->frows || cfg->dtype_mode != 0) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
     c->tWp = t; t += D * P; c->tWout = t; t += P * D;
@@ -835,6 +879,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
       }
     }
     if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
+    if (c->frows) DA(c->colpart, (long long)fused_rows_colpart_floats((int)L, c->BN));
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
@@ -912,7 +957,7 @@ extern "C" int cora_dbg_stamps(cora_ctx* c, unsigned long long* host, size_t n) 
   return 0;
 }
 
-int cora_kernel_path(const cora_ctx* c) { return c ? (c->fused ? 1 : (c->fusedw ? 2 : 0)) : -1; }
+int cora_kernel_path(const cora_ctx* c) { return c ? (c->fused ? 1 : (c->fusedw ? 2 : (c->frows ? 3 : 0))) : -1; }
 
 int cora_sync(cora_ctx* c) {
   if (!c) return -1;
@@ -1160,11 +1205,17 @@ int enqueue_wgrad(cora_ctx* c) {
     if (launch_fused_block(f, L, 1, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     launch_colpart_reduce(f, L, c->st);
   } else {
-    rc = errors_pass(c, slot);   // learning_step_fn evaluates E at the final vodes, :482-483
+    rc = errors_pass(c, slot, c->frows ? 1 : 0);   // learning_step_fn evaluates E at the final vodes, :482-483
     if (rc) return rc;
+    if (c->frows) {   // backward half with the LayerNorm-1 column sums, then every bias / LayerNorm gradient of the blocks
+      if ((rc = block_backward_rows(c, nullptr, 1))) return rc;
+      RowsP r; fill_rows(c, r, nullptr, nullptr);
+      KScope s(c, K_OTHER, 0, 4.0 * fused_rows_colpart_floats(L, c->BN));
+      launch_rows_colpart_reduce(r, c->dW, c->st);
+    }
   }
   // dE/dtheta = -(du/dtheta)^T e
-  if (c->fused) {
+  if (c->fused || c->frows) {
     // the six contractions (K = B*N rows each, 56 output tiles in all) go out as ONE launch, split
     // over K so that the launch has ~1k workgroups; launched one by one each filled a fraction of
     // the chip (64..768 workgroups) and they took 256 us together
@@ -1186,8 +1237,15 @@ int enqueue_wgrad(cora_ctx* c) {
     }
     const int sk = pick_splitk(tiles, (int)c->BN);
     for (int k = 0; k < m.n; ++k) m.p[k].splitk = sk;
-    KScope s(c, K_GEMM_TN, fl, 0);
-    launch_gemm_multi_tn(m, c->st);
+    {
+      KScope s(c, K_GEMM_TN, fl, 0);
+      launch_gemm_multi_tn(m, c->st);
+    }
+    if (c->frows) {   // the edge layers of this path are per-op GEMMs: their bias gradients are plain column sums
+      KScope s(c, K_OTHER, 0, 4.0 * R * (D + P));
+      launch_colsum(err_ptr(c, 1), nullptr, nullptr, c->dW + c->obp, 0, R, 1, D, -1.f, c->st);
+      launch_colsum(err_ptr(c, L + 2), nullptr, nullptr, c->dW + c->obout, 0, R, 1, P, -1.f, c->st);
+    }
     return 0;
   }
   wgrad_gemm(c, 1, err_ptr(c, 1), D, 0, vode_ptr(c, c->Hs, 0), P, 0, c->dW + c->oWp, 0, 0);

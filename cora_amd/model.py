@@ -375,8 +375,9 @@ class TransformerDecoder:
         return rh
 
     def kernel_path(self) -> str:
-        """"fused" (one workgroup per (block, image)) or "per-op" -- which kernels the step runs."""
-        return {1: "fused", 2: "fused-wide"}.get(_lib.load().cora_kernel_path(self._ctx), "per-op")
+        """"fused" / "fused-wide" (one workgroup per (block, image)), "fused-rows" (row-tile kernels around the attention
+        kernels) or "per-op" -- which kernels the step runs."""
+        return {1: "fused", 2: "fused-wide", 3: "fused-rows"}.get(_lib.load().cora_kernel_path(self._ctx), "per-op")
 
     # -- adam state (optimizer state is not part of the reference's checkpoints, but is exposed) ----
     def _reset_adam_state(self):

@@ -266,8 +266,9 @@ int cora_profile_step(cora_ctx* ctx, int cap, char* names, int* launches, double
                       double* flops, double* bytes, int* n_out);
 int cora_sync(cora_ctx* ctx);
 /* Which kernels this ctx's inference step runs: 0 = per-op path (grouped GEMM / attention / LayerNorm
- * launches), 1 = the fused per-(block, image) kernel (D = 64), 2 = its wide variant (D = 96 / 128,
- * inference step only); -1 for a NULL ctx.  For reports and tests. */
+ * launches), 1 = the fused per-(block, image) kernel (D = 64, 64 tokens), 2 = its wide variant (D = 96 / 128,
+ * inference step only), 3 = the row-tile fused kernels around the attention kernels (D = 64, any sequence
+ * length: the 1024-token video shape); -1 for a NULL ctx.  For reports and tests. */
 int cora_kernel_path(const cora_ctx* ctx);
 /* Diagnostic builds only (`make -C cora_amd/csrc stamps`, -DCORA_STAMPS): the first call allocates the
  * per-workgroup s_memtime stamp table of the fused kernel, later calls copy it out ((L+1)*B*16 words).

@@ -43,6 +43,14 @@ FULL_CASES = {
 }
 
 
+# Cases where fp32 itself cannot hold the plain 1e-4 on every tensor: the SAME oracle run in fp32 is further than
+# 1e-4 from its fp64 run (config 5 at its own depth, B = 1: 1024 tokens x 6 blocks x 20 chained steps with the clip
+# firing on a single image's norm -- fp32 oracle vs fp64 oracle: h1 8.0e-4, train_mse 2.1e-4; the HIP path sits AT
+# that floor, 7.2e-4 / 2.1e-4).  No fp32 implementation -- the reference's JAX path included -- can be held to 1e-4
+# against fp64 there, so for these cases EVERY tensor gets the rule final_h_grad gets everywhere:
+# bar = max(1e-4, 3 x fp32-oracle floor).  The rows say which tensors it relaxed ("bar" > 1e-4).
+NOISE_FLOOR_CASES = {"cfg5_video16_N1024_L6_B1_T20"}
+
 # the same cases in the opt-in bf16 mode (bar 1e-2): the shapes its bf16 GEMM + bf16 attention kernels serve,
 # with all T chained steps (the 64-token configs run their fused fp32 kernels only in fp32 mode)
 BF16_FULL_CASES = ["cfg4_imagenet224_L6_B2_T10", "cfg5_video16_N1024_L2_B1_T20", "cfg5_video16_N1024_L6_B1_T20",
@@ -113,7 +121,7 @@ def run_full_case(name: str, compute_dtype: str = "fp32"):
         sc = (np.abs(want).max() + 1e-30) if scale is None else scale
         err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / sc)
         floor = float(np.abs(np.asarray(f32, dtype=np.float64) - want).max() / sc)
-        bar = max(tol, 3.0 * floor) if key.startswith("gh") else tol
+        bar = max(tol, 3.0 * floor) if (key.startswith("gh") or (name in NOISE_FLOOR_CASES and compute_dtype != "bf16")) else tol
         if compute_dtype == "bf16" and key.startswith("gh"):
             bar = None
         rows[key] = {"err": err, "floor": floor, "bar": bar}

@@ -10,7 +10,8 @@ import os
 
 import pytest
 
-from tests.parity_cases import BF16_FULL_CASES, BF16_TOL, BF16X3_FULL_CASES, FULL_CASES, TOL, run_full_case, summarise
+from tests.parity_cases import (BF16_FULL_CASES, BF16_TOL, BF16X3_FULL_CASES, FULL_CASES, NOISE_FLOOR_CASES, TOL,
+                                run_full_case, summarise)
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,14 @@ def test_full_size_oracle_parity(name):
             json.dump({"info": info, "rows": rows}, f, indent=1)
     bad = {k: v for k, v in rows.items() if not v["err"] <= v["bar"]}
     assert not bad, f"{name}: parity failures {bad}"
-    assert all(v["bar"] == TOL for k, v in rows.items() if not k.startswith("gh"))
+    if name in NOISE_FLOOR_CASES:
+        # the fp32 oracle itself misses 1e-4 here (tests/parity_cases.py: NOISE_FLOOR_CASES): only tensors whose
+        # fp32 floor is above 1e-4 / 3 can have been relaxed, and the per-step energies are not among them
+        loose = {k: v for k, v in rows.items() if v["bar"] > TOL and not k.startswith("gh")}
+        assert all(v["floor"] > TOL / 3 for v in loose.values()) and len(loose) <= 4, loose
+        assert rows["energies[T]"]["bar"] == TOL and rows["final_w_energy"]["bar"] == TOL
+    else:
+        assert all(v["bar"] == TOL for k, v in rows.items() if not k.startswith("gh"))
 
 
 @pytest.mark.parametrize("name", BF16_FULL_CASES)

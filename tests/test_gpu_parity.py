@@ -50,6 +50,10 @@ CASES = {
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
+    # the row-tile fused kernels (fused_rows.hip: D = 64, B*N a multiple of 64, any sequence length) around attn.hip
+    "rows_n256_h2_L3": ((4, 3, 32, 32), 4, 64, 2, 3, 1, 3),
+    "rows_n64_P16_h4": ((1, 32, 32), 4, 64, 4, 2, 3, 3),     # 64 tokens but P != 48: not the per-(block, image) kernel
+    "rows_n512_h1_B2": ((8, 3, 32, 32), 4, 64, 1, 2, 2, 3),
     "n144_h4_headdim16": ((3, 48, 48), 4, 64, 4, 2, 2, 3),     # N = 144: two chunks + one 16-row tile, head dim 16
     "n144_h2_headdim32": ((3, 48, 48), 4, 64, 2, 1, 2, 2),
     "n144_h1_headdim96": ((3, 48, 48), 4, 96, 1, 1, 2, 2),     # chunked attention at the wide head dims
@@ -122,7 +126,9 @@ def test_step_parity(name):
 
 
 @pytest.mark.parametrize("name,path", [("d128_h4_P16", "per-op"), ("d96_h2_P192", "per-op"), ("d128_h4_shallow", "fused-wide"),
-                                       ("d128_h1_shallow", "fused-wide"), ("cfg2_shape_B4", "fused")])
+                                       ("d128_h1_shallow", "fused-wide"), ("cfg2_shape_B4", "fused"),
+                                       ("cfg5_video_small", "fused-rows"), ("rows_n64_P16_h4", "fused-rows"),
+                                       ("n144_h4_headdim16", "per-op")])
 def test_wide_kernels_need_patch_dim_48(name, path):
     """cora_kernel_path: the wide fused kernels (D = 96 / 128) take P = 48 only -- their edge layers hard-code the
     4x4x3 patch (fused_wide_common.h: edge_path_wide) -- so a 64-token config with another patch dim (a 1-channel
@@ -133,6 +139,43 @@ def test_wide_kernels_need_patch_dim_48(name, path):
 def test_regularisers_and_clipping():
     # l1/l2 vode regularisers on, and clip thresholds low enough that both clips trigger
     run_case("tiny_2block_h2", l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5)
+
+
+@pytest.mark.parametrize("name", ["rows_n256_h2_L3", "rows_n64_P16_h4"])
+def test_rows_path_regularisers_clip_and_grad_norm(name):
+    """The row-tile fused kernels with everything their epilogues fold in switched on: l1 / l2 vode regularisers
+    (energy in rows_mid, gradient in rows_out), both clips firing, and normalize_vode_h_gradients on top."""
+    run_case(name, l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5, expect_path="fused-rows")
+    run_case(name, use_grad_norm=True, grad_norm_target=1.5, clip_h=2.0, expect_path="fused-rows")
+
+
+def test_rows_path_matches_per_op_path(monkeypatch):
+    """Two independent implementations of the same step -- the row-tile fused kernels and the per-op GEMM /
+    LayerNorm launches (CORA_NO_ROWS=1) -- on the same inputs: vodes, energies, dE/dW after a whole step."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = CASES["rows_n512_h1_B2"]
+    case = make_case(shape, p, D, H, L, B, seed=31)
+    res = []
+    for rows in (True, False):
+        if rows:
+            monkeypatch.delenv("CORA_NO_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("CORA_NO_ROWS", "1")
+        model, ow, oh = build_model(case)
+        assert model.kernel_path() == ("fused-rows" if rows else "per-op")
+        Eh, Ew, gh, gw, mse = ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh)
+        tot, per = ca.step_energies(model, T)
+        res.append(dict(Ew=Ew, mse=mse, tot=tot, per=per, h=[model.vodes[l].h.get() for l in range(L + 2)],
+                        gw={k: gw[k] for k in model.param_keys()}))
+        model.close()
+    a, b = res
+    assert relerr(a["tot"], b["tot"]) <= 1e-5 and relerr(a["per"], b["per"]) <= 1e-5
+    assert abs(a["Ew"] - b["Ew"]) <= 1e-5 * abs(b["Ew"]) and abs(a["mse"] - b["mse"]) <= 1e-5 * abs(b["mse"])
+    for l in range(L + 2):
+        assert relerr(a["h"][l], b["h"][l]) <= 1e-5, l
+    gmax = max(np.abs(v).max() for v in b["gw"].values())
+    for k in b["gw"]:
+        assert np.abs(a["gw"][k] - b["gw"][k]).max() <= 1e-4 * gmax, k
 
 
 BF16_TOL = 1e-2
