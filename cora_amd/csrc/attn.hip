@@ -524,6 +524,134 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-pass backward for long sequences (N a multiple of 64, head dims 16 / 32 / 64; the row-tile path of
+// fused_rows.hip, which supplies delta = rowsum(dO * O) from its own registers): one workgroup owns 16 NW keys
+// and streams Q / dO chunks ONCE -- S and dP are computed once (5 products per (own, streamed) tile pair instead
+// of the 7 of the two-kernel form above).  dV and dK contract over the streamed queries, which is what the score
+// registers are laid out for; dQ contracts over the OWN keys (the lane index), so dS crosses the workgroup
+// through LDS, transposed -- sT[key][q] -- and each wave multiplies a 16-query x 16-column slice of
+// dQ = dS K_own against the workgroup's own K rows (staged once).  The N / (16 NW) key blocks of one
+// (image, head) each hold a partial dQ: they are summed with float atomics into dqa (zeroed by the caller);
+// the order of those adds is the only run-to-run freedom (as in the split-K weight gradients).
+template <int DH, int NW>
+struct AttnSmemF {
+  static constexpr int LD = DH + 4, LT = CH + 4;
+  float s1[CH * LD];             // Q chunk
+  float s2[CH * LD];             // dO chunk
+  float sK[16 * NW * LD];        // own K rows
+  float sT[16 * NW * LT];        // dS^T [own key][query of the chunk], already scaled by 1/sqrt(d)
+  float rowc[2 * CH];            // lse2, delta of the chunk's queries
+};
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2,
+                                                                    const float* __restrict__ dO, const float* __restrict__ delta,
+                                                                    float* __restrict__ dqa, float* __restrict__ dqkv,
+                                                                    int nimg, int N, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  AttnSmemF<DH, NW>& sm = *reinterpret_cast<AttnSmemF<DH, NW>*>(smem_raw);
+  constexpr int LD = DH + 4, LT = CH + 4, NCT = DH / 16;
+  constexpr int NTILE = 4 * NCT;                         // 16 x 16 tiles of the chunk's dQ^T [DH][64]
+  constexpr int TPW = (NTILE + NW - 1) / NW;             // ... per wave
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
+  int rb, h, img;
+  if (!attn_coords((N + 16 * NW - 1) / (16 * NW), H, nimg, rb, h, img)) return;
+  const int ld = 3 * D;
+  const float* base = qkv + (long long)img * N * ld;
+  const float* Q = base + h * DH;
+  const float* K = base + D + h * DH;
+  const float* V = base + 2 * D + h * DH;
+  const float* dOp = dO + (long long)img * N * D + h * DH;
+  const int krow0 = rb * 16 * NW;
+  const int krow = krow0 + 16 * w + c;
+  const float scale = rsqrtf((float)DH);
+  const float sc = scale * CORA_LOG2E;
+
+  float kf[DH / 4], vf[DH / 4];
+  load_frag<DH>(kf, K, ld, krow, N, grp);
+  load_frag<DH>(vf, V, ld, krow, N, grp);
+  for (int f = threadIdx.x; f < 16 * NW * (DH / 4); f += 64 * NW) {      // own K rows, once
+    const int row = f / (DH / 4), c4 = f % (DH / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (krow0 + row < N) v = *reinterpret_cast<const float4*>(K + (long long)(krow0 + row) * ld + 4 * c4);
+    *reinterpret_cast<float4*>(&sm.sK[row * LD + 4 * c4]) = v;
+  }
+  f32x4 dk[NCT], dv[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) { dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const bool key_ok = krow < N;
+
+  StageF<DH, 64 * NW> stg;
+  stg.load(Q, ld, dOp, D, 0, N);
+  for (int q0 = 0; q0 < N; q0 += CH) {
+    __syncthreads();                         // the previous chunk's s1 / s2 / sT are no longer read
+    stg.store(sm.s1, sm.s2);
+    if (threadIdx.x < CH) {
+      const long long ri = ((long long)img * N + q0 + threadIdx.x) * H + h;
+      sm.rowc[threadIdx.x] = lse2[ri];
+      sm.rowc[CH + threadIdx.x] = delta[ri];
+    }
+    __syncthreads();
+    if (q0 + CH < N) stg.load(Q, ld, dOp, D, q0 + CH, N);
+    {
+      f32x4 S[4], dP[4];
+      score_tiles<DH>(S, sm.s1, kf, c, grp);     // S[q][key]
+      score_tiles<DH>(dP, sm.s2, vf, c, grp);    // dP[q][key] = dO[q] . V[key]
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ql = 16 * tt + 4 * grp + reg;
+          const float pv = key_ok ? __builtin_amdgcn_exp2f(S[tt][reg] * sc - sm.rowc[ql]) : 0.f;
+          S[tt][reg] = pv;                                        // P
+          dP[tt][reg] = pv * (dP[tt][reg] - sm.rowc[CH + ql]);    // dS
+        }
+      accum_tiles<DH>(dv, sm.s2, S, c, grp);     // dV^T += dO^T P
+      accum_tiles<DH>(dk, sm.s1, dP, c, grp);    // dK^T += Q^T dS
+      float* trow = &sm.sT[(16 * w + c) * LT + 4 * grp];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        *reinterpret_cast<float4*>(trow + 16 * tt) =
+            make_float4(dP[tt][0] * scale, dP[tt][1] * scale, dP[tt][2] * scale, dP[tt][3] * scale);
+    }
+    __syncthreads();                         // dS^T of all 16 NW own keys visible
+    if (w * TPW < NTILE) {                   // dQ^T[dd][q] += sum_key K[key][dd] dS[q][key] over the workgroup's keys
+      const int qt = (w * TPW) / NCT;
+      f32x4 acc[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int key = 16 * kt + 4 * grp + reg;
+          const float b = sm.sT[key * LT + 16 * qt + c];
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const int ct = (w * TPW + j) % NCT;
+            acc[j] = mfma16(sm.sK[key * LD + 16 * ct + c], b, acc[j]);
+          }
+        }
+      float* qrow = dqa + ((long long)img * N + q0 + 16 * qt + c) * D + h * DH + 4 * grp;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int ct = (w * TPW + j) % NCT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(qrow + 16 * ct + r, acc[j][r]);
+      }
+    }
+  }
+  if (key_ok) {
+    float* drow = dqkv + ((long long)img * N + krow) * ld + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) = make_float4(dk[ct][0] * scale, dk[ct][1] * scale, dk[ct][2] * scale, dk[ct][3] * scale);
+      *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = make_float4(dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int DH, int NW>
 static int run_fwd_w(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
   size_t sm = sizeof(AttnSmem2<DH>);
@@ -582,6 +710,36 @@ static int run_bwd(const float* qkv, const float* O, const float* lse2, const fl
     case 128: return CALL(128);      \
     default: return -1;              \
   }
+
+template <int DH>
+static int run_bwd_fused(const float* qkv, const float* lse2, const float* dO, const float* delta, float* dqa, float* dqkv,
+                         int nimg, int N, int H, int D, hipStream_t st) {
+  constexpr int NW = 8;
+  const size_t sm = sizeof(AttnSmemF<DH, NW>);
+  static bool attr[64] = {};
+  if (first_use_on_device(attr)) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<DH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+  }
+  const int nrb = (N + 16 * NW - 1) / (16 * NW);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NW>), dim3(attn_grid(nrb, H, nimg)), dim3(64 * NW), sm, st, qkv, lse2, dO, delta, dqa,
+                     dqkv, nimg, N, H, D);
+  return 0;
+}
+bool attn_bwd_fused_supported(int N, int H, int D) {
+  const int dh = D / H;
+  return (dh == 16 || dh == 32 || dh == 64) && N > CH && N % CH == 0;
+}
+// dqa: [nimg * N, D] floats, ZEROED by the caller (dQ is summed into it); dqkv receives dk | dv only
+int launch_attn_bwd_fused(const float* qkv, const float* lse2, const float* dO, const float* delta, float* dqa, float* dqkv,
+                          int nimg, int N, int H, int D, hipStream_t st) {
+  if (!attn_bwd_fused_supported(N, H, D)) return -1;
+  switch (D / H) {
+    case 16: return run_bwd_fused<16>(qkv, lse2, dO, delta, dqa, dqkv, nimg, N, H, D, st);
+    case 32: return run_bwd_fused<32>(qkv, lse2, dO, delta, dqa, dqkv, nimg, N, H, D, st);
+    case 64: return run_bwd_fused<64>(qkv, lse2, dO, delta, dqa, dqkv, nimg, N, H, D, st);
+  }
+  return -1;
+}
 
 int launch_attn_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st) {
 #define CALL(X) run_fwd<X>(qkv, O, lse2, nimg, N, H, D, st)

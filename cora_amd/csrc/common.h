@@ -142,6 +142,11 @@ int launch_attn_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, in
 // dqkv: [rows, 3D]; delta: [rows, H] scratch
 int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const float* dO,
                     float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
+// single-pass backward (N % 64 == 0, N > 64, head dim 16 / 32 / 64): delta [rows, H] is an INPUT (rowsum(dO * O), left by
+// rows_mid), dq is summed into dqa [rows, D] (zeroed by the caller), dqkv receives dk | dv
+bool attn_bwd_fused_supported(int N, int H, int D);
+int launch_attn_bwd_fused(const float* qkv, const float* lse2, const float* dO, const float* delta, float* dqa,
+                          float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
 // bf16 mode (attn_bf16.hip): the same backward on bf16 MFMA; -1 (nothing launched) where it does not apply
 bool attn_bwd_bf16_supported(int N, int H, int D);
 bool attn_fwd_bf16_supported(int N, int H, int D);
@@ -258,7 +263,15 @@ struct RowsP {
   float* G1;             // gradients of vodes 1..L: g_{g+1} -> G1 + g nl
   const float* W; const float* WT;
   long long oLn1g, oLn1b, oLn2g, oLn2b, oWqkv, oWo, oW1, ob1, oW2, ob2, tWqkv, tWo, tW1, tW2;
-  float* qkv; const float* att; float* dO; float* rdy; const float* dqkv;   // [L rows, 3D | D | D | D | 3D]
+  float* qkv; const float* att; float* dO; float* rdy; float* dqkv;   // [L rows, 3D | D | D | D | 3D]
+  // edge != 0 (inference launches, P = 48): rows / 64 extra workgroups do the top edge (in rows_qkv: e_1, energy of vode 1
+  // at energy[-1], g_0 and its sum of squares at sumsq[-8 ..]) and the bottom edge (in rows_out: e_img, sensory energy at
+  // esens, g_{L+1} and its sum of squares at sumsq[8 L ..]) instead of four per-op GEMM launches
+  int edge; int N; float s0;
+  const float* H0; const float* XP; const float* pos; float* EIMG; float* G0; double* esens;
+  long long oWp, obp, oWout, obout, tWp, tWout;
+  float* delta; int H;   // not null: rows_mid also leaves delta[row, head] = sum over the head's columns of dO * att
+  const float* dqa;      // not null: rows_out reads dq from here ([L rows, D]; the single-pass attention backward)
   long long rows;        // B * N token rows per block (multiple of 64)
   int L;
   double* energy;        // energy[g] += energy of vode g + 2

@@ -119,6 +119,7 @@ struct cora_ctx {
   bool fused = false;     // D = 64 fused kernel (inference, STORE and chain modes)
   bool fusedw = false;    // D = 96 / 128 fused kernel (inference step only; learning phase and chain stay per-op)
   bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
+  bool frows_bwd1 = false;   // ... with the single-pass attention backward (N a multiple of 64, > 64)
   bool frows = false;     // D = 64 at any sequence length: row-tile fused kernels around attn.hip (fused_rows.hip)
   bool slotted() const { return fused || fusedw; }   // inference-step energies kept as 8 partial sums per vode (esum)
 
@@ -505,13 +506,25 @@ void fill_rows(cora_ctx* c, RowsP& r, double* en2 /* energy of vode 2 */, double
   r.qkv = c->qkv; r.att = c->att; r.dO = c->dO; r.rdy = c->dzn; r.dqkv = c->dqkv;
   r.rows = c->BN; r.L = c->L; r.energy = en2; r.sumsq = ss1; r.gscale = c->gscale; r.l1 = c->cfg.l1; r.l2 = c->cfg.l2;
   r.S_xn1 = c->xn1; r.S_xn2 = c->xn2; r.S_a = c->a; r.S_da = c->da; r.S_dy = c->dy; r.colpart = c->colpart;
+  r.H = c->H;
+  if (c->frows_bwd1) { r.delta = c->delta; r.dqa = c->dxn; }   // single-pass attention backward (attn.hip)
+  // edge layers as extra workgroups of the inference launches (the caller sets r.edge)
+  r.N = c->N; r.s0 = c->scale_l[0]; r.H0 = vode_ptr(c, c->Hs, 0); r.XP = c->xp; r.pos = c->pos;
+  r.EIMG = err_ptr(c, c->L + 2); r.G0 = vode_ptr(c, c->Gs, 0);
+  r.oWp = c->oWp; r.obp = c->obp; r.oWout = c->oWout; r.obout = c->obout; r.tWp = c->tWp; r.tWout = c->tWout;
+}
+// the inference step of the row-tile path folds the two edge layers into its launches (fused_rows.hip: P = 48 only)
+bool rows_edge_fused(const cora_ctx* c) {
+  static const bool off = getenv("CORA_ROWS_NO_EDGE") != nullptr;
+  return c->frows && c->P == 48 && !off;
 }
 // Row-tile path, forward half of all L blocks: q|k|v, attention, then e_{2..L+1}, their energies, dO and r + dy.
 // store: also leave the operands of the weight-gradient contractions (learning phase).
-int block_forward_rows(cora_ctx* c, double* en2, int store) {
+int block_forward_rows(cora_ctx* c, double* en2, int store, double* ss1 = nullptr) {
   const int L = c->L, D = c->D;
   const double rows = (double)L * c->BN;
-  RowsP r; fill_rows(c, r, en2, nullptr);
+  RowsP r; fill_rows(c, r, en2, ss1);
+  r.edge = (ss1 != nullptr && !store && rows_edge_fused(c)) ? 1 : 0;   // top edge: e_1, energy of vode 1, g_0
   { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 4 * D);
     if (launch_rows_qkv(r, store, c->st)) FAIL(-3, "rows_qkv: launch set-up failed"); }
   { KScope s(c, K_ATTN_FWD, 4.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 4 * D);
@@ -522,12 +535,20 @@ int block_forward_rows(cora_ctx* c, double* en2, int store) {
 }
 // ... and the backward half: attention backward, then the vode gradients g_1..g_L with their sums of squares
 // (store: the LayerNorm-1 column sums instead)
-int block_backward_rows(cora_ctx* c, double* ss1, int store) {
+int block_backward_rows(cora_ctx* c, double* ss1, int store, double* esens = nullptr) {
   const int L = c->L, D = c->D;
   const double rows = (double)L * c->BN;
   RowsP r; fill_rows(c, r, nullptr, ss1);
-  { KScope s(c, K_ATTN_BWD, 14.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 9 * D);
-    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward: head dim not supported"); }
+  r.edge = (esens != nullptr && !store && rows_edge_fused(c)) ? 1 : 0;  // bottom edge: e_img, sensory energy, g_{L+1}
+  r.esens = esens;
+  if (c->frows_bwd1) {
+    launch_zero(c->dxn, sizeof(float) * (size_t)(rows * D), c->st);      // dq is summed into it
+    KScope s(c, K_ATTN_BWD, 10.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 8 * D);   // 5 products
+    if (launch_attn_bwd_fused(c->qkv, c->lse, c->dO, c->delta, c->dxn, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward (single pass): launch set-up failed");
+  } else {
+    KScope s(c, K_ATTN_BWD, 14.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 9 * D);
+    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+  }
   { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 7 * D);
     if (launch_rows_out(r, store, c->st)) FAIL(-3, "rows_out: launch set-up failed"); }
   return 0;
@@ -543,17 +564,20 @@ void vode_ln_forward(cora_ctx* c) {
 // what block g / the output projection read: the vode itself, or its normalised copy
 const float* vode_in(cora_ctx* c, int l) { return c->vln ? c->hln + (long long)(l - 1) * c->nl : vode_ptr(c, c->Hs, l); }
 
-int errors_pass(cora_ctx* c, int slot, int store = 0) {
+// ss != null (the inference step of the row-tile path with P = 48): the edge layers ride in the rows launches -- e_1, the
+// energy of vode 1 and g_0 here; e_img, the sensory energy and g_{L+1} in block_backward_rows, which must follow
+int errors_pass(cora_ctx* c, int slot, int store = 0, double* ss = nullptr) {
   const int L = c->L;
   double* en = c->energies + (long long)slot * (L + 3);
+  const bool edge = ss != nullptr && !store && rows_edge_fused(c);
   if (c->vln) vode_ln_forward(c);
-  patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
+  if (!edge) patch_proj(c, vode_ptr(c, c->Hs, 0), err_ptr(c, 1), OUT_ERR, vode_ptr(c, c->Hs, 1), en + 1);
   if (L > 0) {
-    int rc = c->frows ? block_forward_rows(c, en + 2, store)
+    int rc = c->frows ? block_forward_rows(c, en + 2, store, edge ? ss + 8 : nullptr)
                       : block_forward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), OUT_ERR, vode_ptr(c, c->Hs, 2), en + 2);
     if (rc) return rc;
   }
-  out_proj(c, vode_in(c, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
+  if (!edge) out_proj(c, vode_in(c, L + 1), err_ptr(c, L + 2), OUT_ERR, c->xp, en + L + 2);
   return 0;
 }
 
@@ -600,10 +624,13 @@ int infer_grad_step(cora_ctx* c, int t) {
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
     launch_vode_grad(v, c->st);
   } else {
-    int rc0 = errors_pass(c, t);
+    int rc0 = errors_pass(c, t, 0, ss);
     if (rc0) return rc0;
   }
-  if (!c->fused && !c->fusedw) {
+  if (rows_edge_fused(c)) {
+    // row-tile path, P = 48: attention backward, then g_1..g_L and -- in the same launch -- the bottom edge
+    if ((rc = block_backward_rows(c, ss + 8, 0, c->energies + (long long)t * (L + 3) + (L + 2)))) return rc;
+  } else if (!c->fused && !c->fusedw) {
   // vode 0: g_0 = -e_1 Wp   (no own energy: energy_fn=None, src/decoder_transformer.py:143-153)
   GemmP p = gemm_base(c, 1);
   p.A = err_ptr(c, 1); p.C = vode_ptr(c, c->Gs, 0);
@@ -861,6 +888,8 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
   c->frows = (!c->fused && !c->fusedw && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_rows_supported(c->BN, c->D, c->M) &&
               getenv("CORA_NO_FUSED") == nullptr && getenv("CORA_NO_ROWS") == nullptr);
+  c->frows_bwd1 = c->frows && (c->H == 1 || c->H == 2 || c->H == 4) && attn_bwd_fused_supported(c->N, c->H, c->D) &&
+                  getenv("CORA_ATTN_BWD2") == nullptr;
   if (c->fused || c->fusedw || c->frows || cfg->dtype_mode != 0) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;

@@ -24,29 +24,6 @@
 //   e_1 = h_1 - (h_0 Wp^T + bp + pos)          g_0 = -s_0 e_1 Wp              (vode 0 has no own energy)
 //   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by vode_grad_kernel)
 // (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153)
-__device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int rows, int cols, int ldt, int tid) {
-  const int c4n = cols / 4;
-  for (int f = tid; f < rows * c4n; f += 256) {
-    int rr = f / c4n, c4 = f % c4n;
-    *reinterpret_cast<float4*>(&dst[rr * ldt + 4 * c4]) = *reinterpret_cast<const float4*>(src + (long long)rr * cols + 4 * c4);
-  }
-}
-template <int NCT>
-__device__ __forceinline__ void load_rowT_n(float* f, const float* base, int grp) {
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    float4 v = *reinterpret_cast<const float4*>(base + 16 * ct + 4 * grp);
-    f[4 * ct] = v.x; f[4 * ct + 1] = v.y; f[4 * ct + 2] = v.z; f[4 * ct + 3] = v.w;
-  }
-}
-template <int NCT>
-__device__ __forceinline__ void store_rowT_n(const float* f, float* base, int grp) {
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-    *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
-}
-
-
 __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   constexpr int D = 64, P = 48, LP = 52;   // P = 48 patch dim; LP = padded stride of 48-wide tiles
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

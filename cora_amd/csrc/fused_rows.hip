@@ -55,6 +55,105 @@ __device__ __forceinline__ void rows_coords(const RowsP& p, int& g, long long& t
 
 enum { RMODE_INFER = 0, RMODE_STORE = 1 };
 
+// ---- edge layers as extra workgroups of the inference launches (P = 48 only, like fused_block.hip: edge_path) ----
+//   top    (rows_qkv launch): e_1 = h_1 - (h_0 Wp^T + bp + pos), energy of vode 1, g_0 = -s_0 e_1 Wp and its sum of squares
+//   bottom (rows_out launch): e_img = x_patch - (h_{L+1} Wout^T + bout), sensory energy,
+//                             g_{L+1} = s_{L+1} (e_{L+1} + reg - e_img Wout) and its sum of squares
+// (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153).  e_1 must exist before rows_out reads it as
+// the own error of vode 1, and e_{L+1} is written by rows_mid: hence one edge per launch.  Four GEMM launches of
+// 16 k rows x K = 48 / 64 less per inference step (launch-latency bound: 82 of 1 320 us at the video shape).
+__device__ __forceinline__ void rows_edge_top(const RowsP& p, float* lds, long long tile) {
+  constexpr int D = 64, P = 48, LP = 52;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, grp = lane >> 4;
+  float* sWp = lds;                  // [64][LP]   Wp   [D][P]
+  float* sWpT = sWp + 64 * LP;       // [48][LD]   Wp^T [P][D]
+  double* red = reinterpret_cast<double*>(lds + 2 * TILE);     // 8 doubles
+  copy_to_lds(sWp, p.W + p.oWp, 64, P, LP, tid);
+  copy_to_lds(sWpT, p.WT + p.tWp, P, D, LD, tid);
+  const long long row = tile * 64 + 16 * w + i;
+  float h0[12], h1[16], bp[16], ps[16];
+  load_rowT_n<3>(h0, p.H0 + row * P, grp);
+  load_rowT_n<4>(h1, p.X + row * D, grp);
+  load_rowT_n<4>(bp, p.W + p.obp, grp);
+  load_rowT_n<4>(ps, p.pos + (row % p.N) * D, grp);
+  __syncthreads();
+  f32x4 acc[4];
+  float e1[16], u[16];
+  zero4(acc); gemm_tile_g<4, 3, LP>(sWp, h0, acc, i, grp); unpack(acc, u);
+  float en = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    e1[k] = h1[k] - (u[k] + bp[k] + ps[k]);
+    en += 0.5f * e1[k] * e1[k] + p.l1 * fabsf(h1[k]) + p.l2 * h1[k] * h1[k];
+  }
+  store_rowT_n<4>(e1, const_cast<float*>(p.E1) + row * D, grp);
+  zero4(acc); gemm_tile_g<3, 4, LD>(sWpT, e1, acc, i, grp);
+  float g0[12];
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float v = -p.s0 * acc[k][j]; g0[4 * k + j] = v; ss += (double)v * v; }
+  store_rowT_n<3>(g0, p.G0 + row * P, grp);
+  const double et = wave_sum_d((double)en);
+  ss = wave_sum_d(ss);
+  if (lane == 0) { red[w] = et; red[4 + w] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&p.energy[-1], red[0] + red[1] + red[2] + red[3]);                      // energy[] points at vode 2
+    atomicAdd(&p.sumsq[-8 + (int)(tile & 7)], red[4] + red[5] + red[6] + red[7]);     // sumsq[] points at vode 1's slots
+  }
+}
+
+__device__ __forceinline__ void rows_edge_bottom(const RowsP& p, float* lds, long long tile) {
+  constexpr int D = 64, P = 48, LP = 52;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, grp = lane >> 4;
+  float* sWo = lds;                  // [48][LD]   Wout [P][D]
+  float* sWoT = sWo + 48 * LD;       // [64][LP]   Wout^T [D][P]
+  double* red = reinterpret_cast<double*>(lds + 2 * TILE);
+  copy_to_lds(sWo, p.W + p.oWout, P, D, LD, tid);
+  copy_to_lds(sWoT, p.WT + p.tWout, D, P, LP, tid);
+  const long long row = tile * 64 + 16 * w + i;
+  const long long nl = p.rows * D;
+  float hl[16], xp[12], bo[12], eL[16];
+  load_rowT_n<4>(hl, p.X + (long long)p.L * nl + row * D, grp);
+  load_rowT_n<3>(xp, p.XP + row * P, grp);
+  load_rowT_n<3>(bo, p.W + p.obout, grp);
+  load_rowT_n<4>(eL, p.E2 + (long long)(p.L - 1) * nl + row * D, grp);       // e_{L+1}, written by rows_mid
+  __syncthreads();
+  f32x4 acc[4];
+  float ei[12];
+  zero4(acc); gemm_tile_g<3, 4, LD>(sWo, hl, acc, i, grp);
+  float en = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float e = xp[4 * k + j] - (acc[k][j] + bo[4 * k + j]); ei[4 * k + j] = e; en += 0.5f * e * e; }
+  store_rowT_n<3>(ei, p.EIMG + row * P, grp);
+  zero4(acc); gemm_tile_g<4, 3, LP>(sWoT, ei, acc, i, grp);
+  float bpl[16];
+  unpack(acc, bpl);
+  const float s = p.gscale[p.L];
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float h = hl[k];
+    const float sg = (h > 0.f) ? 1.f : ((h < 0.f) ? -1.f : 0.f);
+    const float gv = s * (eL[k] + p.l1 * sg + 2.f * p.l2 * h - bpl[k]);
+    bpl[k] = gv;
+    ss += (double)gv * (double)gv;
+  }
+  store_rowT_n<4>(bpl, p.G1 + (long long)p.L * nl + row * D, grp);
+  const double et = wave_sum_d((double)en);
+  ss = wave_sum_d(ss);
+  if (lane == 0) { red[w] = et; red[4 + w] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(p.esens, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&p.sumsq[(long long)p.L * 8 + (int)(tile & 7)], red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 }  // namespace
 
 // ---- rows_qkv: q | k | v = LN1(x) [Wq | Wk | Wv]^T --------------------------------------------------------
@@ -64,6 +163,10 @@ __global__ __launch_bounds__(256) void rows_qkv_kernel(RowsP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wbuf = lds;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, grp = lane >> 4;
+  if (MODE == RMODE_INFER && (long long)blockIdx.x >= (long long)p.L * (p.rows / 64)) {   // the last rows / 64 workgroups: top edge
+    rows_edge_top(p, lds, (long long)blockIdx.x - (long long)p.L * (p.rows / 64));
+    return;
+  }
   int g; long long tile;
   rows_coords(p, g, tile);
   const long long nl = p.rows * D;
@@ -257,10 +360,21 @@ __global__ __launch_bounds__(256, 2) void rows_mid_kernel(RowsP p) {
     }
   }
   {  // dO = dy Wo ; r + dy goes on to rows_out
-    float dof[16];
+    float dof[16], of[16];
+    if (p.delta) load_rowT(of, p.att + srow_g * D, D, grp);   // again (16 registers through the MLP would cost more)
     PUBLISH(0, t);                                          // Wo^T
     zero4(acc); gemm_tile(t, dy, acc, i, grp); unpack(acc, dof);
     store_rowT(dof, p.dO + srow_g * D, grp);
+    if (p.delta) {   // delta[row, head] = dO . att over the head's columns (what the attention backward subtracts from dP)
+      const int nch = 4 / p.H;                              // 16-column groups per head (H = 1, 2, 4)
+      for (int hh = 0; hh < p.H; ++hh) {
+        float dl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dl += ((k >> 2) / nch == hh) ? dof[k] * of[k] : 0.f;
+        dl = grp_sum(dl);
+        if (grp == 0) p.delta[srow_g * p.H + hh] = dl;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) r[k] += dy[k];
     store_rowT(r, p.rdy + srow_g * D, grp);
@@ -283,6 +397,10 @@ __global__ __launch_bounds__(256) void rows_out_kernel(RowsP p) {
   float* wbuf = lds;
   double* ssh = reinterpret_cast<double*>(lds + 2 * TILE);   // 4 doubles
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, grp = lane >> 4;
+  if (MODE == RMODE_INFER && (long long)blockIdx.x >= (long long)p.L * (p.rows / 64)) {   // the last rows / 64 workgroups: bottom edge
+    rows_edge_bottom(p, lds, (long long)blockIdx.x - (long long)p.L * (p.rows / 64));
+    return;
+  }
   int g; long long tile;
   rows_coords(p, g, tile);
   const long long nl = p.rows * D;
@@ -294,8 +412,13 @@ __global__ __launch_bounds__(256) void rows_out_kernel(RowsP p) {
   const int srow = tid >> 4, scol = 4 * (tid & 15);
   PREFETCH(WqkvT, 3 * D);
   float dq[16], dk[16], dv[16];
-  const float* src = p.dqkv + srow_g * 3 * D;
-  load_rowT(dq, src, D, grp);
+  float* src = p.dqkv + srow_g * 3 * D;
+  if (p.dqa) {
+    load_rowT(dq, p.dqa + srow_g * D, D, grp);
+    if (MODE == RMODE_STORE) store_rowT(dq, src, grp);     // dWqkv contracts the contiguous [dq | dk | dv] rows
+  } else {
+    load_rowT(dq, src, D, grp);
+  }
   load_rowT(dk, src + D, D, grp);
   load_rowT(dv, src + 2 * D, D, grp);
   const float* t;
@@ -378,7 +501,7 @@ __global__ __launch_bounds__(256) void rows_colpart_reduce_kernel(RowsP p, float
 bool fused_rows_supported(long long rows, int D, int M) { return D == 64 && M == 256 && rows > 0 && rows % 64 == 0; }
 size_t fused_rows_colpart_floats(int L, long long rows) { return (size_t)L * (size_t)(rows / 64) * 4 * COLPART; }
 
-static size_t rows_lds_small() { return (size_t)(2 * TILE + 16) * sizeof(float); }
+static size_t rows_lds_small() { return (size_t)(2 * TILE + 16) * sizeof(float); }   // edge workgroups: 6 592 floats + 8 doubles at 2 TILE
 static size_t rows_lds_mid() { return (size_t)(2 * TILE + 448 + 16) * sizeof(float); }
 
 static int rows_attrs() {
@@ -394,7 +517,7 @@ static bool rows_ok(const RowsP& p) { return p.L > 0 && p.rows > 0 && p.rows % 6
 
 int launch_rows_qkv(const RowsP& p, int store, hipStream_t st) {
   if (!rows_ok(p)) return -1;
-  const dim3 grid((unsigned)(p.L * (p.rows / 64)));
+  const dim3 grid((unsigned)((p.L + ((p.edge && !store) ? 1 : 0)) * (p.rows / 64)));
   if (store) hipLaunchKernelGGL(rows_qkv_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_small(), st, p);
   else hipLaunchKernelGGL(rows_qkv_kernel<RMODE_INFER>, grid, dim3(256), rows_lds_small(), st, p);
   return 0;
@@ -408,7 +531,7 @@ int launch_rows_mid(const RowsP& p, int store, hipStream_t st) {
 }
 int launch_rows_out(const RowsP& p, int store, hipStream_t st) {
   if (!rows_ok(p)) return -1;
-  const dim3 grid((unsigned)(p.L * (p.rows / 64)));
+  const dim3 grid((unsigned)((p.L + ((p.edge && !store) ? 1 : 0)) * (p.rows / 64)));
   if (store) hipLaunchKernelGGL(rows_out_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_small(), st, p);
   else hipLaunchKernelGGL(rows_out_kernel<RMODE_INFER>, grid, dim3(256), rows_lds_small(), st, p);
   return 0;

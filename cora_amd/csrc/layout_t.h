@@ -166,4 +166,27 @@ __device__ __forceinline__ void ln_bwd_rowT(const float* dout, const float* gam,
   for (int k = 0; k < 16; ++k) dx[k] = rstd * (dx[k] - m1 - xh[k] * m2);
 }
 
+// ---- rows of other widths (the 48-wide patch vectors of the edge layers) and whole small matrices into LDS ----
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* src, int rows, int cols, int ldt, int tid) {
+  const int c4n = cols / 4;
+  for (int f = tid; f < rows * c4n; f += 256) {
+    int rr = f / c4n, c4 = f % c4n;
+    *reinterpret_cast<float4*>(&dst[rr * ldt + 4 * c4]) = *reinterpret_cast<const float4*>(src + (long long)rr * cols + 4 * c4);
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void load_rowT_n(float* f, const float* base, int grp) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    float4 v = *reinterpret_cast<const float4*>(base + 16 * ct + 4 * grp);
+    f[4 * ct] = v.x; f[4 * ct + 1] = v.y; f[4 * ct + 2] = v.z; f[4 * ct + 3] = v.w;
+  }
+}
+template <int NCT>
+__device__ __forceinline__ void store_rowT_n(const float* f, float* base, int grp) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+    *reinterpret_cast<float4*>(base + 16 * ct + 4 * grp) = make_float4(f[4 * ct], f[4 * ct + 1], f[4 * ct + 2], f[4 * ct + 3]);
+}
+
 }  // namespace

@@ -54,6 +54,8 @@ CASES = {
     "rows_n256_h2_L3": ((4, 3, 32, 32), 4, 64, 2, 3, 1, 3),
     "rows_n64_P16_h4": ((1, 32, 32), 4, 64, 4, 2, 3, 3),     # 64 tokens but P != 48: not the per-(block, image) kernel
     "rows_n512_h1_B2": ((8, 3, 32, 32), 4, 64, 1, 2, 2, 3),
+    "rows_n256_h4": ((4, 3, 32, 32), 4, 64, 4, 2, 1, 3),        # single-pass attention backward at head dim 16
+    "rows_n192_h1": ((3, 3, 32, 32), 4, 64, 1, 2, 1, 3),        # N = 192: the second 128-key block is half empty
     "n144_h4_headdim16": ((3, 48, 48), 4, 64, 4, 2, 2, 3),     # N = 144: two chunks + one 16-row tile, head dim 16
     "n144_h2_headdim32": ((3, 48, 48), 4, 64, 2, 1, 2, 2),
     "n144_h1_headdim96": ((3, 48, 48), 4, 96, 1, 1, 2, 2),     # chunked attention at the wide head dims
@@ -147,6 +149,20 @@ def test_rows_path_regularisers_clip_and_grad_norm(name):
     (energy in rows_mid, gradient in rows_out), both clips firing, and normalize_vode_h_gradients on top."""
     run_case(name, l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5, expect_path="fused-rows")
     run_case(name, use_grad_norm=True, grad_norm_target=1.5, clip_h=2.0, expect_path="fused-rows")
+
+
+@pytest.mark.parametrize("name", ["rows_n512_h1_B2", "rows_n256_h2_L3"])
+def test_rows_path_with_two_kernel_attention_backward(name, monkeypatch):
+    """CORA_ATTN_BWD2=1: the row-tile kernels around the two-kernel attention backward (attn_bwd_q / attn_bwd_kv,
+    S and dP recomputed per side) instead of the single-pass one (dQ summed with float atomics)."""
+    monkeypatch.setenv("CORA_ATTN_BWD2", "1")
+    run_case(name, expect_path="fused-rows")
+
+
+def test_rows_path_with_per_op_edge_layers(monkeypatch):
+    """CORA_ROWS_NO_EDGE=1: the two edge layers as per-op GEMM launches instead of extra workgroups of rows_qkv / rows_out."""
+    monkeypatch.setenv("CORA_ROWS_NO_EDGE", "1")
+    run_case("rows_n512_h1_B2", expect_path="fused-rows")
 
 
 def test_rows_path_matches_per_op_path(monkeypatch):

@@ -18,6 +18,7 @@ SHAPES = {
     "fused_shape": ((3, 32, 32), 4, 64, 1, 3, 3, 4),     # N=64, D=64, H=1: the fused kernel path
     "fused_h4": ((3, 32, 32), 4, 64, 4, 2, 2, 3),        # fused kernel, 4 heads of 16
     "general_h2": ((3, 16, 16), 4, 32, 2, 2, 4, 4),      # general (per-op) path
+    "rows_n256_h2": ((3, 64, 64), 4, 64, 2, 2, 1, 3),    # row-tile fused kernels (edge layers inside their launches)
 }
 
 
