@@ -528,7 +528,9 @@ int block_forward_rows(cora_ctx* c, double* en2, int store, double* ss1 = nullpt
   { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 4 * D);
     if (launch_rows_qkv(r, store, c->st)) FAIL(-3, "rows_qkv: launch set-up failed"); }
   { KScope s(c, K_ATTN_FWD, 4.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 4 * D);
-    if (launch_attn_fwd(c->qkv, c->att, c->lse, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention: head dim not supported"); }
+    if (c->cfg.dtype_mode == 1 && attn_fwd_bf16_supported(c->N, c->H, D)) {   // bf16 mode: bf16-MFMA attention between the fp32 row kernels
+      if (launch_attn_fwd_bf16(c->qkv, c->att, c->lse, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention (bf16): launch set-up failed");
+    } else if (launch_attn_fwd(c->qkv, c->att, c->lse, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention: head dim not supported"); }
   { KScope s(c, K_ROWS, rows * (4.0 * D * D + 8.0 * D * c->M), 4.0 * rows * 6 * D);
     if (launch_rows_mid(r, store, c->st)) FAIL(-3, "rows_mid: launch set-up failed"); }
   return 0;
@@ -547,7 +549,9 @@ int block_backward_rows(cora_ctx* c, double* ss1, int store, double* esens = nul
     if (launch_attn_bwd_fused(c->qkv, c->lse, c->dO, c->delta, c->dxn, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward (single pass): launch set-up failed");
   } else {
     KScope s(c, K_ATTN_BWD, 14.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 9 * D);
-    if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+    if (c->cfg.dtype_mode == 1 && attn_bwd_bf16_supported(c->N, c->H, D)) {
+      if (launch_attn_bwd_bf16(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward (bf16): launch set-up failed");
+    } else if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
   }
   { KScope s(c, K_ROWS, 2.0 * rows * D * 3 * D, 4.0 * rows * 7 * D);
     if (launch_rows_out(r, store, c->st)) FAIL(-3, "rows_out: launch set-up failed"); }
@@ -886,10 +890,15 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   c->fusedw = (!c->fused && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_wide_supported(c->N, c->P, c->D, c->H, c->M) &&
                getenv("CORA_NO_FUSED") == nullptr);
   c->fusedw2 = c->fusedw && fused_wide2_supported(c->N, c->P, c->D, c->H, c->M) && getenv("CORA_WIDE1") == nullptr;
-  c->frows = (!c->fused && !c->fusedw && c->L > 0 && cfg->dtype_mode == 0 && !c->vln && fused_rows_supported(c->BN, c->D, c->M) &&
+  // bf16 mode (dtype_mode 1) takes the row kernels too where its bf16-MFMA attention applies (sequences longer than one
+  // chunk): the row-local GEMMs then run on the fp32 MFMA kernels -- more accurate than the mode asks for, and at
+  // D = 64 faster than the per-op bf16 GEMMs they replace -- with the bf16 attention kernels between them
+  const bool rows_dtype = cfg->dtype_mode == 0 ||
+                          (cfg->dtype_mode == 1 && attn_fwd_bf16_supported(c->N, c->H, c->D) && attn_bwd_bf16_supported(c->N, c->H, c->D));
+  c->frows = (!c->fused && !c->fusedw && c->L > 0 && rows_dtype && !c->vln && fused_rows_supported(c->BN, c->D, c->M) &&
               getenv("CORA_NO_FUSED") == nullptr && getenv("CORA_NO_ROWS") == nullptr);
-  c->frows_bwd1 = c->frows && (c->H == 1 || c->H == 2 || c->H == 4) && attn_bwd_fused_supported(c->N, c->H, c->D) &&
-                  getenv("CORA_ATTN_BWD2") == nullptr;
+  c->frows_bwd1 = c->frows && cfg->dtype_mode == 0 && (c->H == 1 || c->H == 2 || c->H == 4) &&
+                  attn_bwd_fused_supported(c->N, c->H, c->D) && getenv("CORA_ATTN_BWD2") == nullptr;
   if (c->fused || c->fusedw || c->frows || cfg->dtype_mode != 0) {   // transposed weight copies: fused kernels' backward GEMMs; bf16 mode's backward-data GEMMs
     size_t t = 0;
     c->tWqkv = t; t += L * 3 * D * D; c->tWo = t; t += L * D * D; c->tW1 = t; t += L * M * D; c->tW2 = t; t += L * D * M;
