@@ -143,9 +143,11 @@ int launch_attn_fwd(const float* qkv, float* O, float* lse2, int nimg, int N, in
 int launch_attn_bwd(const float* qkv, const float* O, const float* lse2, const float* dO,
                     float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
 // single-pass backward (N % 64 == 0, N > 64, head dim 16 / 32 / 64): delta [rows, H] is an INPUT (rowsum(dO * O), left by
-// rows_mid), dq is summed into dqa [rows, D] (zeroed by the caller), dqkv receives dk | dv
+// rows_mid); dq leaves as attn_bwd_fused_parts(N) partial copies [rows, D] at dqa + k * pstride (their sum is dq: one per
+// block of 128 own keys, plain stores, deterministic); dqkv receives dk | dv
 bool attn_bwd_fused_supported(int N, int H, int D);
-int launch_attn_bwd_fused(const float* qkv, const float* lse2, const float* dO, const float* delta, float* dqa,
+int attn_bwd_fused_parts(int N);
+int launch_attn_bwd_fused(const float* qkv, const float* lse2, const float* dO, const float* delta, float* dqa, long long pstride,
                           float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
 // bf16 mode (attn_bf16.hip): the same backward on bf16 MFMA; -1 (nothing launched) where it does not apply
 bool attn_bwd_bf16_supported(int N, int H, int D);
@@ -271,7 +273,7 @@ struct RowsP {
   const float* H0; const float* XP; const float* pos; float* EIMG; float* G0; double* esens;
   long long oWp, obp, oWout, obout, tWp, tWout;
   float* delta; int H;   // not null: rows_mid also leaves delta[row, head] = sum over the head's columns of dO * att
-  const float* dqa;      // not null: rows_out reads dq from here ([L rows, D]; the single-pass attention backward)
+  const float* dqa; int ndq; long long dq_stride;   // not null: rows_out sums dq from ndq partial copies [L rows, D], dq_stride apart
   long long rows;        // B * N token rows per block (multiple of 64)
   int L;
   double* energy;        // energy[g] += energy of vode g + 2

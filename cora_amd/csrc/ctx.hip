@@ -134,6 +134,7 @@ struct cora_ctx {
   float *xn1, *st1, *qkv, *att, *lse, *y, *xn2, *st2, *a;
   float *da, *dzn, *dy, *dO, *delta, *dqkv, *dxn;
   float *ua, *ub, *z, *stash = nullptr;
+  float* dqparts = nullptr;  // row-tile path, single-pass attention backward: ceil(N / 128) partial copies of dq, [L B N, D] each
   unsigned long long* dbg = nullptr;
   float* gscale = nullptr;   // [L] layer scale of the vode each block reads
   float* eta_dev = nullptr;  // [Tmax]
@@ -507,7 +508,9 @@ void fill_rows(cora_ctx* c, RowsP& r, double* en2 /* energy of vode 2 */, double
   r.rows = c->BN; r.L = c->L; r.energy = en2; r.sumsq = ss1; r.gscale = c->gscale; r.l1 = c->cfg.l1; r.l2 = c->cfg.l2;
   r.S_xn1 = c->xn1; r.S_xn2 = c->xn2; r.S_a = c->a; r.S_da = c->da; r.S_dy = c->dy; r.colpart = c->colpart;
   r.H = c->H;
-  if (c->frows_bwd1) { r.delta = c->delta; r.dqa = c->dxn; }   // single-pass attention backward (attn.hip)
+  if (c->frows_bwd1) {   // single-pass attention backward (attn.hip): dq as per-key-block partial copies
+    r.delta = c->delta; r.dqa = c->dqparts; r.ndq = attn_bwd_fused_parts(c->N); r.dq_stride = (long long)c->L * c->nl;
+  }
   // edge layers as extra workgroups of the inference launches (the caller sets r.edge)
   r.N = c->N; r.s0 = c->scale_l[0]; r.H0 = vode_ptr(c, c->Hs, 0); r.XP = c->xp; r.pos = c->pos;
   r.EIMG = err_ptr(c, c->L + 2); r.G0 = vode_ptr(c, c->Gs, 0);
@@ -544,9 +547,8 @@ int block_backward_rows(cora_ctx* c, double* ss1, int store, double* esens = nul
   r.edge = (esens != nullptr && !store && rows_edge_fused(c)) ? 1 : 0;  // bottom edge: e_img, sensory energy, g_{L+1}
   r.esens = esens;
   if (c->frows_bwd1) {
-    launch_zero(c->dxn, sizeof(float) * (size_t)(rows * D), c->st);      // dq is summed into it
-    KScope s(c, K_ATTN_BWD, 10.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 8 * D);   // 5 products
-    if (launch_attn_bwd_fused(c->qkv, c->lse, c->dO, c->delta, c->dxn, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward (single pass): launch set-up failed");
+    KScope s(c, K_ATTN_BWD, 10.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * (7 + attn_bwd_fused_parts(c->N)) * D);   // 5 products
+    if (launch_attn_bwd_fused(c->qkv, c->lse, c->dO, c->delta, c->dqparts, (long long)L * c->nl, c->dqkv, L * c->B, c->N, c->H, D, c->st)) FAIL(-3, "attention backward (single pass): launch set-up failed");
   } else {
     KScope s(c, K_ATTN_BWD, 14.0 * L * c->B * (double)c->N * c->N * D, 4.0 * rows * 9 * D);
     if (c->cfg.dtype_mode == 1 && attn_bwd_bf16_supported(c->N, c->H, D)) {
@@ -918,6 +920,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     }
     if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
     if (c->frows) DA(c->colpart, (long long)fused_rows_colpart_floats((int)L, c->BN));
+    if (c->frows_bwd1) DA(c->dqparts, (long long)attn_bwd_fused_parts(c->N) * (long long)L * c->nl);
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);

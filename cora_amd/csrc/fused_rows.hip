@@ -413,8 +413,14 @@ __global__ __launch_bounds__(256) void rows_out_kernel(RowsP p) {
   PREFETCH(WqkvT, 3 * D);
   float dq[16], dk[16], dv[16];
   float* src = p.dqkv + srow_g * 3 * D;
-  if (p.dqa) {
+  if (p.dqa) {   // single-pass attention backward: dq = sum of its per-key-block partial copies
     load_rowT(dq, p.dqa + srow_g * D, D, grp);
+    for (int kb = 1; kb < p.ndq; ++kb) {
+      float part[16];
+      load_rowT(part, p.dqa + kb * p.dq_stride + srow_g * D, D, grp);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dq[k] += part[k];
+    }
     if (MODE == RMODE_STORE) store_rowT(dq, src, grp);     // dWqkv contracts the contiguous [dq | dk | dv] rows
   } else {
     load_rowT(dq, src, D, grp);

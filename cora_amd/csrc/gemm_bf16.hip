@@ -141,8 +141,13 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       float4 v = ra[i];
-      if (p.a_gelu) { v.x = cora_gelu(v.x); v.y = cora_gelu(v.y); v.z = cora_gelu(v.z); v.w = cora_gelu(v.w); }
       const int o = (srow + RSTEP * i) * LDR + 4 * skq;
+#ifdef EXP_NOCVT   /* timing experiment (scripts/gemm_bf16_bench.hip): A as if pre-split by its producer -- no VALU between load and LDS */
+      *reinterpret_cast<uint2*>(&Ah[o]) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+      if (SPLIT) *reinterpret_cast<uint2*>(&Al[o]) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+      continue;
+#endif
+      if (p.a_gelu) { v.x = cora_gelu(v.x); v.y = cora_gelu(v.y); v.z = cora_gelu(v.z); v.w = cora_gelu(v.w); }
       const bf16x4 h = to_bf16(v);
       *reinterpret_cast<bf16x4*>(&Ah[o]) = h;
       if (SPLIT) {

@@ -79,7 +79,11 @@ __device__ __forceinline__ void gemm_ep_tile(const GemmP& p, const GemmEp& q, co
     case OUT_GELUGRAD: {
       EP_FETCH(t0, q.aux);
 #pragma unroll
+#ifdef EXP_NOGELUGRAD   /* timing experiment: gelu'(a) as if left by the MLP1 epilogue */
+      for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * t0[i]);
+#else
       for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * cora_gelu_grad(t0[i]));
+#endif
     } break;
     case OUT_GRAD: {
       float hr[16];
