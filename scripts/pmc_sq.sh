@@ -9,9 +9,9 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"][:40]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:48]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 for k, d in agg.items():
-    if "pc_block" in k or "gemm" in k:
+    if "pc_block" in k or "gemm" in k or "rows_" in k or "attn" in k:
         print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
 PY

@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_{tag}_{c}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(float); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         agg[k] += float(r["Counter_Value"]); cnt[k] += 1
     for k in agg:
         out.setdefault(k, {})[c + "_per_launch_KB"] = agg[k] / cnt[k]
