@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     "fused_shape": ((3, 32, 32), 4, 64, 1, 2, 4, 3),
     "general_h2": ((3, 16, 16), 4, 32, 2, 2, 4, 3),
+    "rows_n256_h2": ((4, 3, 32, 32), 4, 64, 2, 2, 2, 3),     # row-tile fused kernels: 2 ranks x 1 image of 256 tokens
 }
 
 

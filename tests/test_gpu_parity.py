@@ -275,7 +275,7 @@ def test_vode_grad_norm_option(name):
     run_case(name, use_grad_norm=True, grad_norm_target=1.5, clip_h=2.0)
 
 
-@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4"])
+@pytest.mark.parametrize("name", ["tiny_2block_h2", "cfg2_shape_B4", "rows_n256_h2_L3"])
 def test_ipc_mode_weight_update_every_step(name):
     """MODE 1 of train_on_batch (`update_weights_every_inference_step`, reference :418-439) against the
     oracle: vodes and energies to the fp32 bar.  AdamW's first steps turn every gradient entry into
