@@ -244,6 +244,8 @@ struct FusedP {
   unsigned long long* dbg;   // diagnostic builds only (-DCORA_STAMPS)
 };
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
+// CORA_PAIR=1: the experimental 8-wave form of the inference kernel (fused_block.hip, block_body_pair); off by default
+bool fused_pair_wanted(int L, int B);
 int launch_chain(const FusedP& p, int store_h, hipStream_t st);
 // wide variant (fused_wide.hip): N = 64, D = 96 / 128, inference step only; uses H1, E2, BP1, W, WT, S_stash, S_da
 bool fused_wide_supported(int N, int P, int D, int H, int M);

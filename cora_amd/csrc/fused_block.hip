@@ -583,6 +583,428 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #undef PREFETCH
 #undef PUBLISH
 
+
+// ---- experimental small-batch form of the inference step: one (block, image) on EIGHT waves -----------------
+// With fewer than ~2 x 256 workgroups the 4-wave kernel leaves one wave per SIMD and every MFMA -> LDS -> VALU
+// dependency is exposed (B = 25 per GPU is what an 8-GPU run of the reference's batch of 200 hands each rank).
+// This form puts two waves on each SIMD inside one workgroup.  It did NOT pay (see fused_pair_wanted below).
+// Here wave W = (row group w = W & 3, half hf = W >> 2): both halves hold the same 16 token rows, and every GEMM is
+// split between them the way tensor parallelism splits a transformer block:
+//   column-parallel (input whole, each half produces ITS 32 output columns): Wq|Wk|Wv, W1, W2^T, Wo^T
+//   row-parallel    (each half contracts over ITS 32 input columns, partial sums added):  Wo, W2, W1^T, Wqkv^T
+// so a column-parallel product feeds a row-parallel one with no exchange (q/k/v -> attention of the half's own
+// heads -> Wo; W1 -> gelu -> W2; W2^T -> gelu' -> W1^T; Wo^T -> attention backward -> Wqkv^T) and the halves meet
+// only at the five row-wide points (y, z, dzn, dxn; with one head also S and dP, whose 64 columns span both halves):
+// PAIR_SUM = both write their 16 partial values per lane to LDS, one barrier, each adds the partner's.  a + b and
+// b + a round alike, so both halves carry bit-identical rows through the duplicated LayerNorm / softmax work.
+// Weight tiles are staged once per workgroup (512 threads, two float4 each).  MODE_INFER only.
+template <int NC>
+__device__ __forceinline__ void gemm_tile_hc(const float* __restrict__ t, const float* xf, f32x4* acc, int i, int grp, int ct0) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {   // xf is compact: xf[4 c + reg] belongs to column 16 (ct0 + c) + 4 grp + reg
+    const int ct = ct0 + c;
+    float4 a[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) a[ot] = *reinterpret_cast<const float4*>(&t[(16 * ot + i) * LD + 16 * ct + 4 * grp]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].x, xf[4 * c + 0], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].y, xf[4 * c + 1], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].z, xf[4 * c + 2], acc[ot]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mfma16(a[ot].w, xf[4 * c + 3], acc[ot]);
+  }
+}
+// the half's 32 output columns of a 64x64 weight tile, whole 64-wide input
+__device__ __forceinline__ void gemm_cols_half(const float* __restrict__ t, const float* xf, float* out8, int i, int grp, int hf) {
+  f32x4 a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  gemm_tile_g<2, 4, LD>(t + 32 * hf * LD, xf, a2, i, grp);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out8[4 * c + reg] = a2[c][reg];
+}
+__device__ __forceinline__ void load_half(float* f8, const float* base, int grp, int hf) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float4 v = *reinterpret_cast<const float4*>(base + 16 * (2 * hf + c) + 4 * grp);
+    f8[4 * c] = v.x; f8[4 * c + 1] = v.y; f8[4 * c + 2] = v.z; f8[4 * c + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void store_half(const float* f8, float* base, int grp, int hf) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    *reinterpret_cast<float4*>(base + 16 * (2 * hf + c) + 4 * grp) = make_float4(f8[4 * c], f8[4 * c + 1], f8[4 * c + 2], f8[4 * c + 3]);
+}
+// the half's own 8 entries of a whole row held in registers (wave-uniform select, no dynamic register index)
+__device__ __forceinline__ void pick_half(const float* f16, float* f8, int hf) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f8[k] = hf ? f16[8 + k] : f16[k];
+}
+
+template <int H>
+__device__ __forceinline__ void block_body_pair(const FusedP& p, float* lds, int g, int b) {
+  constexpr int D = 64, M = 256;
+  constexpr int HH = (H == 1) ? 1 : H / 2;   // heads a half works on (one head: both halves, 32 of its 64 columns each)
+  constexpr int NCL = 2 / HH;                // 16-column groups of one head inside a half
+  constexpr float qscale = (H == 1) ? 0.125f : (H == 2 ? 0.17677669529663687f : 0.25f);
+  float* bufK = lds;
+  float* bufV = lds + TILE;
+  float* wbuf = lds + 2 * TILE;          // 2 tiles; Q and dO of the attention backward alias them
+  float* bufQ = lds + 2 * TILE;
+  float* bufDO = lds + 3 * TILE;
+  float* xch = lds + 4 * TILE;           // 2 tiles: the halves' partial rows for PAIR_SUM
+  float* rowc = lds + 6 * TILE;          // lse2[H][64], delta[H][64]
+  float* pb = rowc + 512;                // [b1 256 | ln2 gamma 64 | ln2 beta 64 | b2 64 | ln1 gamma 64]
+  constexpr int PB_LN2G = 256, PB_LN2B = 320, PB_B2 = 384, PB_LN1G = 448;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, hf = tid >> 8;
+  const int i = lane & 15, grp = lane >> 4;
+  const int ct0 = 2 * hf;                // first of the half's two 16-column groups
+  const int lrow = 16 * w + i;
+  const long long nl = (long long)p.B * 64 * D;
+  const long long rowoff = ((long long)b * 64 + lrow) * D;
+  const long long voff = (long long)g * nl + rowoff;
+  const float* xrow = p.H1 + voff;
+  const float* hnext = p.H1 + voff + nl;
+
+  const float* Wqkv = p.W + p.oWqkv + (long long)g * 3 * D * D;
+  const float* Wo = p.W + p.oWo + (long long)g * D * D;
+  const float* W1 = p.W + p.oW1 + (long long)g * M * D;
+  const float* W2 = p.W + p.oW2 + (long long)g * D * M;
+  const float* W2T = p.WT + p.tW2 + (long long)g * M * D;
+  const float* W1T = p.WT + p.tW1 + (long long)g * D * M;
+  const float* WoT = p.WT + p.tWo + (long long)g * D * D;
+  const float* WqkvT = p.WT + p.tWqkv + (long long)g * D * 3 * D;
+  const float* ln1g = p.W + p.oLn1g + (long long)g * D;
+  const float* ln1b = p.W + p.oLn1b + (long long)g * D;
+  if (tid < 128) {
+    const float* src = tid < 64 ? p.W + p.ob1 + (long long)g * M + 4 * tid
+                     : tid < 80 ? p.W + p.oLn2g + (long long)g * D + 4 * (tid - 64)
+                     : tid < 96 ? p.W + p.oLn2b + (long long)g * D + 4 * (tid - 80)
+                     : tid < 112 ? p.W + p.ob2 + (long long)g * D + 4 * (tid - 96)
+                                 : ln1g + 4 * (tid - 112);
+    *reinterpret_cast<float4*>(pb + 4 * tid) = *reinterpret_cast<const float4*>(src);
+  }
+
+  // weight tiles: thread t stages float4 #t and #t+512 of the 64x64 tile (rows t >> 4 and 32 + (t >> 4))
+  float4 sr0, sr1;
+  const int srow = tid >> 4, scol = 4 * (tid & 15);
+#define PREFETCH2(SRC, LDW)                                                                       \
+  do {                                                                                            \
+    const float* s_ = (SRC) + (long long)srow * (LDW) + scol;                                     \
+    sr0 = *reinterpret_cast<const float4*>(s_);                                                   \
+    sr1 = *reinterpret_cast<const float4*>(s_ + 32LL * (LDW));                                    \
+  } while (0)
+#define PUBLISH2(S, TPTR)                                                                         \
+  do {                                                                                            \
+    float* d_ = wbuf + S * TILE + srow * LD + scol;                                               \
+    *reinterpret_cast<float4*>(d_) = sr0;                                                         \
+    *reinterpret_cast<float4*>(d_ + 32 * LD) = sr1;                                               \
+    __syncthreads();                                                                              \
+    TPTR = wbuf + S * TILE;                                                                       \
+  } while (0)
+  // V (16 partial values per lane, the same row in both halves) <- own + partner's.  The exchange tile of a half is
+  // rewritten only after a later barrier (every pair of PAIR_SUMs has a weight-tile barrier in between).
+#define PAIR_SUM(V)                                                                               \
+  do {                                                                                            \
+    store_rowT(V, xch + hf * TILE + lrow * LD, grp);                                              \
+    __syncthreads();                                                                              \
+    float o_[16];                                                                                 \
+    load_rowT(o_, xch + (hf ^ 1) * TILE + lrow * LD, D, grp);                                     \
+    _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) V[k_] += o_[k_];                            \
+  } while (0)
+
+  PREFETCH2(Wqkv, D);
+  const float* t;
+  f32x4 acc[4];
+  const float sc = qscale * CORA_LOG2E;
+
+  // ---- forward ---------------------------------------------------------------------------------------
+  float x[16], y[16];
+  float q8[8];                   // own columns of q, kept for the attention backward
+  float a_keep[32];              // gelu'(a) of the half's 4 x 32 hidden units
+  float pkeep[16 * HH];          // P of the half's head(s): registers, not the stash (half the gelu' leaves the room)
+  load_rowT(x, xrow, D, grp);
+  {
+    float xin[16];
+    {
+      float gm[16], bt[16], xh[17];
+      load_rowT(gm, ln1g, D, grp);
+      load_rowT(bt, ln1b, D, grp);
+      ln_rowT(x, gm, bt, xh, xin);
+    }
+    float o8[8];
+    {
+      float k8[8];
+      PUBLISH2(0, t); PREFETCH2(Wqkv + 64 * D, D);
+      gemm_cols_half(t, xin, q8, i, grp, hf);
+      PUBLISH2(1, t); PREFETCH2(Wqkv + 128 * D, D);
+      gemm_cols_half(t, xin, k8, i, grp, hf);
+      store_half(k8, &bufK[lrow * LD], grp, hf);
+      PUBLISH2(0, t); PREFETCH2(Wo, D);
+      gemm_cols_half(t, xin, k8, i, grp, hf);
+      store_half(k8, &bufV[lrow * LD], grp, hf);
+    }
+    __syncthreads();   // K, V of all 64 tokens visible
+#pragma unroll
+    for (int hh = 0; hh < HH; ++hh) {
+      float pf[16];
+      zero4(acc); gemm_tile_hc<NCL>(bufK, q8 + 4 * NCL * hh, acc, i, grp, ct0 + NCL * hh); unpack(acc, pf);
+      if (H == 1) PAIR_SUM(pf);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
+      mx = grp_max(mx);
+      float ls = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
+      ls = grp_sum(ls);
+      const float inv = 1.0f / ls;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { pf[k] *= inv; pkeep[16 * hh + k] = pf[k]; }
+      if (H > 1 && grp == 0) rowc[64 * (HH * hf + hh) + lrow] = mx + __builtin_amdgcn_logf(ls);
+      f32x4 oa[NCL];
+#pragma unroll
+      for (int c = 0; c < NCL; ++c) oa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accum_tile_h<NCL>(bufV, pf, oa, i, grp, ct0 + NCL * hh);
+#pragma unroll
+      for (int c = 0; c < NCL; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) o8[4 * (NCL * hh + c) + reg] = oa[c][reg];
+    }
+    PUBLISH2(1, t); PREFETCH2(W1, D);   // Wo
+    zero4(acc); gemm_tile_hc<2>(t, o8, acc, i, grp, ct0); unpack(acc, y);
+    PAIR_SUM(y);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += x[k];
+  }
+  float hn[16];
+  {
+    float zn[16];
+    {
+      float gm[16], bt[16], xh[17];
+      load_rowT(gm, pb + PB_LN2G, D, grp);
+      load_rowT(bt, pb + PB_LN2B, D, grp);
+      ln_rowT(y, gm, bt, xh, zn);
+    }
+    load_rowT(hn, hnext, D, grp);
+    f32x4 zacc[4];
+    zero4(zacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      PUBLISH2(0, t);                                        // W1[mt]
+      PREFETCH2(W2 + mt * 64, M);
+      float am[8];
+      {
+        float b1[8];
+        load_half(b1, pb + 64 * mt, grp, hf);
+        gemm_cols_half(t, zn, am, i, grp, hf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) am[k] += b1[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        f32x2 g2, gp2;
+        cora_gelu_both2((f32x2){am[k], am[k + 1]}, g2, gp2);
+        am[k] = g2.x; am[k + 1] = g2.y;
+        a_keep[8 * mt + k] = gp2.x; a_keep[8 * mt + k + 1] = gp2.y;
+      }
+      PUBLISH2(1, t);                                        // W2[:, mt]
+      if (mt < 3) PREFETCH2(W1 + (mt + 1) * 64 * D, D);
+      else PREFETCH2(W2T, D);
+      gemm_tile_hc<2>(t, am, zacc, i, grp, ct0);
+    }
+    float z[16], b2[16];
+    unpack(zacc, z);
+    PAIR_SUM(z);
+    load_rowT(b2, pb + PB_B2, D, grp);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = x[k] + y[k] + z[k] + b2[k];     // u
+  }
+  float r[16];
+  {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = hn[k] - x[k];
+    float r8[8];
+    pick_half(r, r8, hf);
+    store_half(r8, p.E2 + (long long)g * nl + rowoff, grp, hf);
+  }
+
+  // ---- backward (cotangent r) -----------------------------------------------------------------------
+  float dy[16];
+  {
+    f32x4 dacc[4];
+    zero4(dacc);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      PUBLISH2(0, t);                                        // W2^T[mt]
+      PREFETCH2(W1T + mt * 64, M);
+      float dg[8];
+      gemm_cols_half(t, r, dg, i, grp, hf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dg[k] *= a_keep[8 * mt + k];
+      PUBLISH2(1, t);                                        // W1^T[:, mt]
+      if (mt < 3) PREFETCH2(W2T + (mt + 1) * 64 * D, D); else PREFETCH2(WoT, D);
+      gemm_tile_hc<2>(t, dg, dacc, i, grp, ct0);
+    }
+    float dzn[16], gm[16], bt[16], xh[17], tmp[16];
+    unpack(dacc, dzn);
+    PAIR_SUM(dzn);
+    load_rowT(gm, pb + PB_LN2G, D, grp);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bt[k] = 0.f;
+    ln_rowT(y, gm, bt, xh, tmp);
+    ln_bwd_rowT(dzn, gm, xh, dy);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dy[k] += r[k];
+  }
+  float dq8[8], dk8[8], dv8[8];
+  float dsk[H == 1 ? 16 : 1];
+  {
+    float dof[8];
+    PUBLISH2(0, t); PREFETCH2(WqkvT, 3 * D);         // Wo^T; the next tile waits in registers through the attention backward
+    gemm_cols_half(t, dy, dof, i, grp, hf);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] += dy[k];
+    __syncthreads();   // every wave is done with the weight buffers: reuse them for Q and dO
+    store_half(dof, &bufDO[lrow * LD], grp, hf);
+    store_half(q8, &bufQ[lrow * LD], grp, hf);
+    // pass A (own queries): dP, delta, dS, dQ for the half's head(s)
+#pragma unroll
+    for (int hh = 0; hh < HH; ++hh) {
+      float dp[16];
+      const float* pf = pkeep + 16 * hh;
+      zero4(acc); gemm_tile_hc<NCL>(bufV, dof + 4 * NCL * hh, acc, i, grp, ct0 + NCL * hh); unpack(acc, dp);
+      if (H == 1) PAIR_SUM(dp);
+      float dl = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+      dl = grp_sum(dl);
+      if (H > 1 && grp == 0) rowc[64 * H + 64 * (HH * hf + hh) + lrow] = dl;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);
+      f32x4 qa[NCL];
+#pragma unroll
+      for (int c = 0; c < NCL; ++c) qa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accum_tile_h<NCL>(bufK, dp, qa, i, grp, ct0 + NCL * hh);
+#pragma unroll
+      for (int c = 0; c < NCL; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dq8[4 * (NCL * hh + c) + reg] = qa[c][reg] * qscale;
+      if (H == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dsk[k] = dp[k];
+      }
+    }
+  }
+  __syncthreads();   // Q, dO rows and delta of all tokens visible; K and V no longer read (one head)
+  if (H == 1) {
+    // pass B, one head: P (written by half 0) and dS (half 1) cross from the query owners to the key owners through
+    // the dead K / V tiles; each half then produces its 32 columns of dV = P^T dO and dK = dS^T Q
+    if (hf == 0) store_rowT(pkeep, &bufK[lrow * LD], grp);
+    else store_rowT(dsk, &bufV[lrow * LD], grp);
+    __syncthreads();
+    float sp[16], dp[16];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        sp[4 * tt + reg] = bufK[(16 * tt + 4 * grp + reg) * LD + lrow];
+        dp[4 * tt + reg] = bufV[(16 * tt + 4 * grp + reg) * LD + lrow];
+      }
+    f32x4 va[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ka[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    accum_tile_h<2>(bufDO, sp, va, i, grp, ct0);
+    accum_tile_h<2>(bufQ, dp, ka, i, grp, ct0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { dv8[4 * c + reg] = va[c][reg]; dk8[4 * c + reg] = ka[c][reg] * qscale; }
+  }
+#pragma unroll
+  for (int hh = 0; hh < (H == 1 ? 0 : HH); ++hh) {
+    // pass B, several heads: S, dP of the half's head recomputed with the key on the lane; dV, dK
+    const int hg = HH * hf + hh, ch = ct0 + NCL * hh;
+    float sp[16], dp[16];
+    {
+      float kf[4 * NCL], vf[4 * NCL];
+#pragma unroll
+      for (int c = 0; c < NCL; ++c) {
+        float4 kv = *reinterpret_cast<const float4*>(&bufK[lrow * LD + 16 * (ch + c) + 4 * grp]);
+        float4 vv = *reinterpret_cast<const float4*>(&bufV[lrow * LD + 16 * (ch + c) + 4 * grp]);
+        kf[4 * c] = kv.x; kf[4 * c + 1] = kv.y; kf[4 * c + 2] = kv.z; kf[4 * c + 3] = kv.w;
+        vf[4 * c] = vv.x; vf[4 * c + 1] = vv.y; vf[4 * c + 2] = vv.z; vf[4 * c + 3] = vv.w;
+      }
+      zero4(acc); gemm_tile_hc<NCL>(bufQ, kf, acc, i, grp, ch); unpack(acc, sp);      // S[q][key]
+      zero4(acc); gemm_tile_hc<NCL>(bufDO, vf, acc, i, grp, ch); unpack(acc, dp);     // dP[q][key]
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      float4 l4 = *reinterpret_cast<const float4*>(&rowc[64 * hg + 16 * tt + 4 * grp]);
+      float4 d4 = *reinterpret_cast<const float4*>(&rowc[64 * H + 64 * hg + 16 * tt + 4 * grp]);
+      float pv;
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 0] * sc - l4.x); sp[4 * tt + 0] = pv; dp[4 * tt + 0] = pv * (dp[4 * tt + 0] - d4.x);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 1] * sc - l4.y); sp[4 * tt + 1] = pv; dp[4 * tt + 1] = pv * (dp[4 * tt + 1] - d4.y);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
+      pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
+    }
+    f32x4 va[NCL], ka[NCL];
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) { va[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; ka[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    accum_tile_h<NCL>(bufDO, sp, va, i, grp, ch);
+    accum_tile_h<NCL>(bufQ, dp, ka, i, grp, ch);
+#pragma unroll
+    for (int c = 0; c < NCL; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        dv8[4 * (NCL * hh + c) + reg] = va[c][reg];
+        dk8[4 * (NCL * hh + c) + reg] = ka[c][reg] * qscale;
+      }
+  }
+  __syncthreads();     // Q / dO no longer read: the buffers go back to the weight pipeline
+  {  // dxn = [dq | dk | dv] Wqkv (each half its own columns of the three K-chunks), dx = r + dy + LN1^T(dxn)
+    zero4(acc);
+    PUBLISH2(1, t); PREFETCH2(WqkvT + 64, 3 * D);
+    gemm_tile_hc<2>(t, dq8, acc, i, grp, ct0);
+    PUBLISH2(0, t); PREFETCH2(WqkvT + 128, 3 * D);
+    gemm_tile_hc<2>(t, dk8, acc, i, grp, ct0);
+    PUBLISH2(1, t);
+    gemm_tile_hc<2>(t, dv8, acc, i, grp, ct0);
+    float dxn[16], gm[16], bt[16], xh[17], xv[16], tmp[16], dx[16];
+    unpack(acc, dxn);
+    PAIR_SUM(dxn);
+    load_rowT(xv, xrow, D, grp);
+    load_rowT(gm, pb + PB_LN1G, D, grp);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bt[k] = 0.f;
+    ln_rowT(xv, gm, bt, xh, tmp);
+    ln_bwd_rowT(dxn, gm, xh, dx);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dx[k] += r[k];        // r holds r + dy
+    float dx8[8];
+    pick_half(dx, dx8, hf);
+    store_half(dx8, p.BP1 + (long long)g * nl + rowoff, grp, hf);
+  }
+}
+#undef PREFETCH2
+#undef PUBLISH2
+#undef PAIR_SUM
+
+template <int H>
+__global__ __launch_bounds__(512) void pc_block_pair_kernel(FusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= p.L * p.B) {   // edge layers of one image: the first four waves, as in the 4-wave kernel
+    if (threadIdx.x >= 256) return;
+    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
+    return;
+  }
+  int j = (int)blockIdx.x;
+  const int n = p.L * p.B;
+  if ((n & 7) == 0) j = (j & 7) * (n >> 3) + (j >> 3);
+  block_body_pair<H>(p, lds, j / p.B, j % p.B);
+}
+
 template <int MODE, int H>
 __global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -659,6 +1081,18 @@ __global__ __launch_bounds__(256, 1) void pc_chain_kernel(FusedP p, int store_h)
 
 
 size_t fused_block_lds_bytes() { return (size_t)(4 * TILE + 128 * 4 + 512) * sizeof(float); }   // rowc sized for 4 heads + parameter block
+static size_t fused_pair_lds_bytes() { return (size_t)(6 * TILE + 128 * 4 + 512) * sizeof(float); }
+
+// Opt-in (CORA_PAIR=1), off by default: measured on MI355X (profiles/r3_pair_sweep.txt) the 8-wave form gains 1.7 % at
+// B = 25 (6 blocks: 150 workgroups, one per CU either way) and loses 7-13 % from B = 42 up.  The two halves of a row
+// group sit on the same SIMD in lockstep -- same barriers, MFMA and VALU phases at the same time -- so they hide
+// little of each other's latency, and the row-wide work they both carry (LayerNorm, one-head softmax, the exchanges)
+// is paid twice on that SIMD.  Kept, with its parity tests, as the reproducible record of that experiment.
+bool fused_pair_wanted(int L, int B) {
+  (void)L; (void)B;
+  const char* e = getenv("CORA_PAIR");   // read per launch (launches are captured into graphs, so this is off the hot path)
+  return e && *e && atoi(e) != 0;
+}
 
 template <int H>
 static int launch_fused_h(const FusedP& p, int L, int store, hipStream_t st) {
@@ -668,8 +1102,13 @@ static int launch_fused_h(const FusedP& p, int L, int store, hipStream_t st) {
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_chain_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_pair_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_pair_lds_bytes()) != hipSuccess) return -1;
   }
   if (L < 0) return 0;   // attribute set-up only
+  if (!store && fused_pair_wanted(L, p.B)) {
+    hipLaunchKernelGGL(pc_block_pair_kernel<H>, dim3((L + 1) * p.B), dim3(512), fused_pair_lds_bytes(), st, p);
+    return 0;
+  }
   if (store == 2) hipLaunchKernelGGL(pc_chain_kernel<H>, dim3(p.B), dim3(256), sm, st, p, L /* store_h */);
   else if (store) hipLaunchKernelGGL((pc_block_fused_kernel<MODE_STORE, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   else hipLaunchKernelGGL((pc_block_fused_kernel<MODE_INFER, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
