@@ -205,12 +205,19 @@ void launch_patchify(const float* img, float* xp, int B, int F, int C, int Himg,
 
 // ---- vode update ----------------------------------------------------------------------------------
 // per-leaf multipliers: optional per-leaf normalisation, then the global-norm clip over all leaves
-// (mult[nlayers] is the un-frozen sensory leaf's, layer scale included).  One thread.
-__device__ void vode_multipliers(const UpdateP& p, float* mult) {
+// (mult[nlayers] is the un-frozen sensory leaf's, layer scale included).  One thread, reading the slots from the
+// block's LDS copy (ss: [nlayers][8], se: [sens_n]) -- straight from global memory the layer loop was a chain of
+// nlayers dependent L2 round trips at the head of every block (a third of the kernel at small batches).
+constexpr int MULT_MAX_LAYERS = 65;
+__device__ void stage_multiplier_inputs(const UpdateP& p, double* ss, double* se) {
+  for (int j = threadIdx.x; j < p.nlayers * 8; j += blockDim.x) ss[j] = p.sumsq[j];
+  if (p.sens_e && (int)threadIdx.x < p.sens_n) se[threadIdx.x] = p.sens_e[threadIdx.x];
+}
+__device__ void vode_multipliers(const UpdateP& p, float* mult, const double* ss, const double* se) {
   double tot = 0.0;
   for (int l = 0; l < p.nlayers; ++l) {
     double n2 = 0.0;
-    for (int k = 0; k < 8; ++k) n2 += p.sumsq[l * 8 + k];
+    for (int k = 0; k < 8; ++k) n2 += ss[l * 8 + k];
     float m = 1.f;
     if (p.use_grad_norm) {
       double nrm = sqrt(n2);
@@ -223,7 +230,7 @@ __device__ void vode_multipliers(const UpdateP& p, float* mult) {
   mult[p.nlayers] = 0.f;
   if (p.sens_e) {
     double es = 0.0;
-    for (int k = 0; k < p.sens_n; ++k) es += p.sens_e[k];
+    for (int k = 0; k < p.sens_n; ++k) es += se[k];
     double n2 = 2.0 * (double)p.sens_s * (double)p.sens_s * es;
     float m = 1.f;
     if (p.use_grad_norm) {
@@ -243,7 +250,8 @@ __device__ void vode_multipliers(const UpdateP& p, float* mult) {
 }
 
 __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
-  __shared__ float mult_sh[66];
+  __shared__ float mult_sh[MULT_MAX_LAYERS + 1];
+  __shared__ double ss_sh[MULT_MAX_LAYERS * 8], se_sh[8];
   const long long n4 = (p.n0 + (long long)(p.nlayers - 1) * p.nl) / 4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   constexpr int NS = 4;   // independent float4 triples in flight per thread (swept with the grid: 4 x 1024 blocks is the fastest at cfg 2)
@@ -263,7 +271,9 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   // the first (usually only) batch of loads is issued BEFORE the per-leaf multipliers are worked out by
   // thread 0: they do not depend on them, and the block's start-up then costs one memory latency, not two
   fetch();
-  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
+  stage_multiplier_inputs(p, ss_sh, se_sh);
+  __syncthreads();
+  if (threadIdx.x == 0) vode_multipliers(p, mult_sh, ss_sh, se_sh);
   __syncthreads();
   const float eta = p.eta[p.t];
   while (i0 < n4) {
@@ -285,8 +295,11 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
 }
 __global__ __launch_bounds__(256) void sens_update_kernel(UpdateP p, float* __restrict__ hs, float* __restrict__ ms,
                                                           const float* __restrict__ e_img, long long n4) {
-  __shared__ float mult_sh[66];
-  if (threadIdx.x == 0) vode_multipliers(p, mult_sh);
+  __shared__ float mult_sh[MULT_MAX_LAYERS + 1];
+  __shared__ double ss_sh[MULT_MAX_LAYERS * 8], se_sh[8];
+  stage_multiplier_inputs(p, ss_sh, se_sh);
+  __syncthreads();
+  if (threadIdx.x == 0) vode_multipliers(p, mult_sh, ss_sh, se_sh);
   __syncthreads();
   const float mul = mult_sh[p.nlayers], eta = p.eta[p.t];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -391,6 +404,11 @@ void launch_vode_grad(const VodeGradP& p, hipStream_t st) {
   long long bx = (nl4 + 4095) / 4096;   // four float4 per thread and iteration, four iterations per thread (swept: 14.5 us against 16.1 at one)
   if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
+  if (bx * p.nlay < 256) {   // small batches: fill the chip (>= 2 blocks per CU) before giving a thread a second iteration
+    const long long fine = (nl4 + 255) / 256, want = (512 + p.nlay - 1) / p.nlay;
+    bx = fine < want ? fine : want;
+    if (bx < 1) bx = 1;
+  }
   hipLaunchKernelGGL(vode_grad_kernel, dim3((unsigned)bx, p.nlay), dim3(256), 0, st, p);
 }
 
