@@ -183,6 +183,8 @@ struct UpdateP {
   // the global norm.  Its gradient is g_s = sens_s * e_img, so ||g_s||^2 = 2 sens_s^2 * (1/2 sum e_img^2),
   // and the sensory energy is already reduced into sens_e[0..sens_n).  Null: sensory vode frozen.
   const double* sens_e; int sens_n; float sens_s;
+  float* h_out; float* m_out;   // null: in place; else the updated vodes / momentum go here (launch_update only)
+  float* g_out;                 // not null: the gradients are copied here on the way through
 };
 void launch_update(const UpdateP& p, hipStream_t st);
 // sensory state (patch layout, n floats): m_s = c g_s + mu m_s ; h_s -= eta m_s, same multipliers as launch_update
@@ -242,6 +244,15 @@ struct FusedP {
   // chain kernel: z [B*N, P] and the clipped squared reconstruction error
   float* Z; double* mse;
   unsigned long long* dbg;   // diagnostic builds only (-DCORA_STAMPS)
+  // lazy != 0 (inference step t + 1 of the D = 64 path): the vode update of step t is applied as the rows are loaded --
+  // h' = h - eta (mult g + mu m) from the OLD arenas (H1 / H0, Mo1 / M0o, Go1 / G0o; up = the parameters and the
+  // sums-of-squares row of step t), and the workgroup that reads a vode as its INPUT writes h', m' to the NEW arenas
+  // (Hn1 / H0n, Mn1 / M0n); BP1 / G0 point into the new gradient arena.  Saves the update kernel's launch and hides its
+  // HBM traffic under the MFMA-bound block kernel.
+  int lazy;
+  const float* Mo1; const float* Go1; float* Hn1; float* Mn1;
+  const float* M0o; const float* G0o; float* H0n; float* M0n;
+  UpdateP up;
 };
 int launch_fused_block(const FusedP& p, int L, int store, hipStream_t st);
 // CORA_PAIR=1: the experimental 8-wave form of the inference kernel (fused_block.hip, block_body_pair); off by default

@@ -125,6 +125,17 @@ struct cora_ctx {
 
   // vodes
   float *Hs = nullptr, *Ms = nullptr, *Gs = nullptr, *Es = nullptr;  // Es: e_1..e_{L+1} then e_img
+  // D = 64 fused path, deferred vode update (FusedP::lazy): inside a T-step loop the update of step t is applied by the
+  // inference launch of step t + 1 as it loads its rows, out of place -- so vodes, momentum and gradients ping-pong
+  // between two sets of arenas.  `cur` is the set the vodes live in (always 0 between API calls: the last step of a loop
+  // updates explicitly, into set 0), `pend` the step whose update is waiting, `lazy_T` the length of the running loop
+  // (0: every update is launched as its own kernel, as on every other path).
+  float *Hs2 = nullptr, *Ms2 = nullptr, *Gs2 = nullptr;
+  bool lazy_ok = false;
+  int lazy_T = 0, pend = -1, cur = 0;
+  float* Hc() const { return cur ? Hs2 : Hs; }
+  float* Mc() const { return cur ? Ms2 : Ms; }
+  float* Gc() const { return cur ? Gs2 : Gs; }
   float* xp = nullptr;     // target, patch layout [BN, P]
   float* ximg = nullptr;   // image staging [B, F*C*H*W]
   long long nImg;
@@ -223,7 +234,11 @@ int dalloc(cora_ctx* c, float** p, long long n) {
 
 // A cora_infer(out = NULL) may still be in flight and still reads the pinned staging buffers and the
 // vodes: every entry point that touches vodes, eta_dev, xp or the energy log ends it first.
+int flush_lazy_update(cora_ctx* c);
+void fill_update(cora_ctx* c, UpdateP& u, int t);
 int settle_pending(cora_ctx* c) {
+  if (int rc_ = flush_lazy_update(c)) return rc_;   // a split-API loop abandoned between cora_infer_update and the next cora_infer_grad
+  c->lazy_T = 0;
   if (!c->infer_pending) return 0;
   HCHECK(hipSetDevice(c->device));
   HCHECK(hipStreamSynchronize(c->st));
@@ -481,13 +496,13 @@ int energy_row(cora_ctx* c, int slot, double* en) {
 void fill_fused(cora_ctx* c, FusedP& f, double* en /* energy row of this pass */, double* ss /* sumsq row */) {
   const int L = c->L;
   memset(&f, 0, sizeof f);
-  f.H1 = vode_ptr(c, c->Hs, 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gs, 1); f.W = c->W; f.WT = c->WT;
+  f.H1 = vode_ptr(c, c->Hc(), 1); f.E2 = err_ptr(c, 2); f.BP1 = vode_ptr(c, c->Gc(), 1); f.W = c->W; f.WT = c->WT;
   f.oLn1g = c->oLn1g; f.oLn1b = c->oLn1b; f.oLn2g = c->oLn2g; f.oLn2b = c->oLn2b; f.oWqkv = c->oWqkv; f.oWo = c->oWo;
   f.oW1 = c->oW1; f.ob1 = c->ob1; f.oW2 = c->oW2; f.ob2 = c->ob2;
   f.tWqkv = c->tWqkv; f.tWo = c->tWo; f.tW1 = c->tW1; f.tW2 = c->tW2;
   f.energy = en ? en + 2 : nullptr; f.esens = nullptr; f.B = c->B; f.l1 = c->cfg.l1; f.l2 = c->cfg.l2;
-  f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hs, 0); f.XP = c->xp; f.pos = c->pos;
-  f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gs, 0); f.sumsq0 = ss;
+  f.L = L; f.s0 = c->scale_l[0]; f.H0 = vode_ptr(c, c->Hc(), 0); f.XP = c->xp; f.pos = c->pos;
+  f.E1 = err_ptr(c, 1); f.EIMG = err_ptr(c, L + 2); f.G0 = vode_ptr(c, c->Gc(), 0); f.sumsq0 = ss;
   f.oWp = c->oWp; f.obp = c->obp; f.oWout = c->oWout; f.obout = c->obout; f.tWp = c->tWp; f.tWout = c->tWout;
   f.S_xn1 = c->xn1; f.S_att = c->att; f.S_xn2 = c->xn2; f.S_a = c->a; f.S_da = c->da;
   f.S_dy = c->dy; f.S_dqkv = c->dqkv;
@@ -600,13 +615,24 @@ int infer_grad_step(cora_ctx* c, int t) {
     FusedP f;
     fill_fused(c, f, nullptr, ss);
     f.esens = es + (long long)(L + 2) * 8;
+    const bool lazy = c->pend >= 0;
+    if (lazy) {   // the update of step `pend` rides in this launch: old arenas in, the other set out
+      float *Ho = c->Hc(), *Mo = c->Mc(), *Go = c->Gc();
+      c->cur ^= 1;
+      float *Hn = c->Hc(), *Mn = c->Mc(), *Gn = c->Gc();
+      f.lazy = 1;
+      f.H0 = Ho; f.H1 = Ho + c->n0; f.M0o = Mo; f.Mo1 = Mo + c->n0; f.G0o = Go; f.Go1 = Go + c->n0;
+      f.H0n = Hn; f.Hn1 = Hn + c->n0; f.M0n = Mn; f.Mn1 = Mn + c->n0; f.G0 = Gn; f.BP1 = Gn + c->n0;
+      fill_update(c, f.up, c->pend);
+      c->pend = -1;
+    }
     {
       double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
-      KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl);
+      KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0));
       if (launch_fused_block(f, L, 0, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);
-    v.bp = vode_ptr(c, c->Gs, 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hs, 1); v.g = vode_ptr(c, c->Gs, 1);
+    v.bp = vode_ptr(c, c->Gc(), 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hc(), 1); v.g = vode_ptr(c, c->Gc(), 1);
     v.gscale = c->gscale; v.nl = c->nl; v.nlay = L + 1; v.l1 = c->cfg.l1; v.l2 = c->cfg.l2;
     v.sumsq = ss + 8; v.esum = es + 8;
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
@@ -675,13 +701,23 @@ int infer_grad_step(cora_ctx* c, int t) {
 
 // second half: clip by the global norm (row t of c->sumsq -- summed over ranks first in the exact
 // data-parallel mode), momentum SGD on every vode
+void fill_update(cora_ctx* c, UpdateP& u, int t) {
+  const int L = c->L;
+  memset(&u, 0, sizeof u);
+  u.h = c->Hc(); u.m = c->Mc(); u.g = c->Gc(); u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
+  u.sumsq = c->sumsq + (long long)t * (L + 2) * 8; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
+  u.use_grad_norm = c->cfg.use_grad_norm; u.grad_norm_target = c->cfg.grad_norm_target;
+}
 int infer_update_step(cora_ctx* c, int t) {
   const int L = c->L;
-  double* ss = c->sumsq + (long long)t * (L + 2) * 8;
-  UpdateP u; memset(&u, 0, sizeof u);
-  u.h = c->Hs; u.m = c->Ms; u.g = c->Gs; u.n0 = c->n0; u.nl = c->nl; u.nlayers = L + 2;
-  u.sumsq = ss; u.clip = c->cfg.clip_h; u.mu = c->cfg.momentum; u.eta = c->eta_dev; u.t = t;
-  u.use_grad_norm = c->cfg.use_grad_norm; u.grad_norm_target = c->cfg.grad_norm_target;
+  if (c->lazy_ok && t + 1 < c->lazy_T && !c->sens_live) {   // D = 64 fused path: the next inference launch applies it
+    c->pend = t;
+    return 0;
+  }
+  UpdateP u;
+  fill_update(c, u, t);
+  // last step of a loop with deferred updates: back into set 0, the gradient included (cora_get_vode_grad reads it there)
+  if (c->cur) { u.h_out = c->Hs; u.m_out = c->Ms; u.g_out = c->Gs; }
   if (c->sens_live) {   // un-frozen sensory vode: one more leaf in the clip norm, then its own update
     if (c->slotted()) { u.sens_e = c->esum + ((long long)t * (L + 3) + (L + 2)) * 8; u.sens_n = 8; }
     else { u.sens_e = c->energies + (long long)t * (L + 3) + (L + 2); u.sens_n = 1; }
@@ -691,11 +727,20 @@ int infer_update_step(cora_ctx* c, int t) {
     KScope s(c, K_UPDATE, 0, 20.0 * c->nV);
     launch_update(u, c->st);
   }
+  c->cur = 0;
   if (c->sens_live) {
     KScope s(c, K_OTHER, 0, 20.0 * c->n0);
     launch_sens_update(u, c->xp, c->msens, err_ptr(c, L + 2), c->n0, c->st);
   }
   return 0;
+}
+int flush_lazy_update(cora_ctx* c) {
+  if (c->pend < 0) return 0;
+  const int t = c->pend, keep = c->lazy_T;
+  c->pend = -1; c->lazy_T = 0;
+  int rc = infer_update_step(c, t);
+  c->lazy_T = keep;
+  return rc;
 }
 
 int infer_step(cora_ctx* c, int t) {
@@ -717,11 +762,11 @@ int enqueue_infer(cora_ctx* c, int T) {
   // vodes up at step 1 of a later batch; tests/test_gpu_parity.py::test_graph_replay_matches_eager
   // guards this.
   zero_infer_logs(c, T);
-  for (int t = 0; t < T; ++t) {
-    int rc = infer_step(c, t);
-    if (rc) return rc;
-  }
-  return 0;
+  c->lazy_T = T;   // steps 0 .. T-2 may hand their vode update to the next step's launch (D = 64 fused path)
+  int rc = 0;
+  for (int t = 0; t < T && !rc; ++t) rc = infer_step(c, t);
+  c->lazy_T = 0;
+  return rc;
 }
 
 // status "forward" chain (rule 'h -> u', :167-168,175-176): u_1 from h_0, each block reads the
@@ -923,6 +968,11 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
     if (c->frows_bwd1) DA(c->dqparts, (long long)attn_bwd_fused_parts(c->N) * (long long)L * c->nl);
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
+  // second arena set of the deferred vode update (see cora_ctx::Hs2); the experimental 8-wave kernel has no such form
+  if (c->fused && !getenv("CORA_NO_LAZY") && !fused_pair_wanted((int)L, c->B)) {
+    DA(c->Hs2, c->nV); DA(c->Ms2, c->nV); DA(c->Gs2, c->nV);
+    c->lazy_ok = true;
+  }
   DA(c->Es, (long long)(L + 1) * c->nl + c->n0);
   if (c->vln) { DA(c->hln, (long long)(L + 1) * c->nl); DA(c->stv, 2LL * (L + 1) * c->BN); DA(c->dxr, (long long)(L + 1) * c->nl); }
   DA(c->xp, c->n0); DA(c->ximg, c->nImg);
@@ -1578,6 +1628,7 @@ int cora_infer_begin(cora_ctx* c, const float* x, int x_on_device, int T, const 
   c->last_T = T;
   HCHECK(hipEventRecord(c->ev0, c->st));
   zero_infer_logs(c, T);
+  c->lazy_T = T;   // until cora_infer_end (or any other entry point: settle_pending)
   return 0;
 }
 int cora_infer_grad(cora_ctx* c, int t) {
@@ -1606,6 +1657,8 @@ int cora_infer_update(cora_ctx* c, int t) {
 int cora_infer_end(cora_ctx* c, cora_step_out* out) {
   if (!c) return -1;
   HCHECK(hipSetDevice(c->device));
+  if (int rc_ = flush_lazy_update(c)) return rc_;   // a loop cut short of its last step
+  c->lazy_T = 0;
   HCHECK(hipEventRecord(c->ev1, c->st));
   HCHECK(hipStreamSynchronize(c->st));
   if (out && c->last_T > 0) {
@@ -1728,15 +1781,18 @@ int cora_comm_info(const cora_ctx* c, int* rank, int* world) {
 static int enqueue_infer_dist(cora_ctx* c, int T, bool exact) {
   zero_infer_logs(c, T);
   const size_t nrow = (size_t)(c->L + 2) * 8;
+  c->lazy_T = T;   // a deferred update reads row t after its all-reduce: same stream, launched later
   for (int t = 0; t < T; ++t) {
     int rc = infer_grad_step(c, t);
-    if (rc) return rc;
+    if (rc) { c->lazy_T = 0; return rc; }
     if (exact) {
       double* row = c->sumsq + (long long)t * nrow;
-      NCHECK(g_rccl.AllReduce(row, row, nrow, ncclDouble, ncclSum, c->comm, c->st));
+      ncclResult_t r_ = g_rccl.AllReduce(row, row, nrow, ncclDouble, ncclSum, c->comm, c->st);
+      if (r_ != ncclSuccess) { c->lazy_T = 0; c->err = std::string("ncclAllReduce (sums of squares) failed: ") + g_rccl.GetErrorString(r_); return -5; }
     }
-    if ((rc = infer_update_step(c, t))) return rc;
+    if ((rc = infer_update_step(c, t))) { c->lazy_T = 0; return rc; }
   }
+  c->lazy_T = 0;
   return 0;
 }
 // dE/dW of this shard, SUM over ranks, then the identical clip + AdamW step (scale 1 / (B_local * world),
@@ -2112,6 +2168,8 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   HCHECK(hipMemsetAsync(c->sumsq, 0, sizeof(double) * (c->L + 2) * 8, c->st));
   HCHECK(hipMemsetAsync(c->esum, 0, sizeof(double) * (c->L + 3) * 8, c->st));
   const int tp = 0;
+  c->lazy_T = 2;       // profile the steady state of a T-step loop: where the path defers the vode update into the next
+                       // step's launch (D = 64 fused), every profiled step carries the previous one's
   infer_step(c, tp);   // warm
   HCHECK(hipStreamSynchronize(c->st));
   c->prof = true; c->recs.clear();
@@ -2119,6 +2177,8 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   int rc = 0;
   for (int i = 0; i < reps && !rc; ++i) rc = infer_step(c, tp);
   c->prof = false;
+  if (!rc) rc = flush_lazy_update(c);
+  c->lazy_T = 0;
   HCHECK(hipStreamSynchronize(c->st));
   for (int k = 0; k < K_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; snprintf(names + 32 * k, 32, "%s", kKindNames[k]); }
   for (auto& r : c->recs) {

@@ -18,12 +18,17 @@
 #include "common.h"
 
 #include "layout_t.h"
+#include "vode_mult.h"
+
 
 
 // ---- edge layers of one image: vode 0 <-> vode 1 (patch projection) and vode L+1 <-> sensory ------
 //   e_1 = h_1 - (h_0 Wp^T + bp + pos)          g_0 = -s_0 e_1 Wp              (vode 0 has no own energy)
 //   e_img = x_patch - (h_{L+1} Wout^T + bout)   bp_{L+1} = e_img Wout          (finished by vode_grad_kernel)
 // (/root/reference/src/decoder_transformer.py:222-228, 244-256, 143-153)
+// LAZY: the rows come in as h - eta (mult g + mu m) of the previous step (FusedP::lazy); this workgroup is the one that
+// reads vode 0 and vode L+1 as INPUTS, so it writes their new values and momenta; vode 1 it only reads (as a target).
+template <bool LAZY>
 __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   constexpr int D = 64, P = 48, LP = 52;   // P = 48 patch dim; LP = padded stride of 48-wide tiles
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -42,6 +47,25 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
   load_rowT_n<4>(h1, p.H1 + tok * D, grp);
   load_rowT_n<4>(hl, p.H1 + (long long)p.L * p.B * 64 * D + tok * D, grp);
   load_rowT_n<3>(xp, p.XP + tok * P, grp);
+  if (LAZY) {
+    const long long oL = (long long)p.L * p.B * 64 * D + tok * D;
+    float g0[12], m0[12], g1[16], m1[16], gl[16], ml[16];
+    load_rowT_n<3>(g0, p.G0o + tok * P, grp); load_rowT_n<3>(m0, p.M0o + tok * P, grp);
+    load_rowT_n<4>(g1, p.Go1 + tok * D, grp); load_rowT_n<4>(m1, p.Mo1 + tok * D, grp);
+    load_rowT_n<4>(gl, p.Go1 + oL, grp); load_rowT_n<4>(ml, p.Mo1 + oL, grp);
+    float c0, c1, cl;
+    vode_multipliers_wave(p.up, 0, 1, p.L + 1, c0, c1, cl);
+    const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { m0[k] = g0[k] * c0 + mu * m0[k]; h0[k] -= eta * m0[k]; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      m1[k] = g1[k] * c1 + mu * m1[k]; h1[k] -= eta * m1[k];
+      ml[k] = gl[k] * cl + mu * ml[k]; hl[k] -= eta * ml[k];
+    }
+    store_rowT_n<3>(h0, p.H0n + tok * P, grp); store_rowT_n<3>(m0, p.M0n + tok * P, grp);
+    store_rowT_n<4>(hl, p.Hn1 + oL, grp); store_rowT_n<4>(ml, p.Mn1 + oL, grp);
+  }
   __syncthreads();
   f32x4 acc[4];
   // ---- top: e_1, energy of vode 1, g_0
@@ -102,7 +126,8 @@ __device__ __forceinline__ void edge_path(const FusedP& p, float* lds, int b) {
 //   MODE_INFER: x = h_{g+1} from HBM; writes e_{g+2}, its energy and J^T e (the inference step)
 //   MODE_STORE: the same, and also leaves every tensor the weight-gradient GEMMs need in HBM
 //   MODE_CHAIN: x comes in registers (xio), forward only, the prediction u goes back in xio
-enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
+//   MODE_LAZY:  MODE_INFER that first applies the previous step's vode update to the rows it loads (FusedP::lazy)
+enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2, MODE_LAZY = 3 };
 
 // Diagnostic build only (-DCORA_STAMPS): wave 0 of each workgroup records s_memtime at phase
 // boundaries into p.dbg[blockIdx.x * 16 + k].  Never compiled into the shipped library.
@@ -132,6 +157,7 @@ enum { MODE_INFER = 0, MODE_STORE = 1, MODE_CHAIN = 2 };
 template <int MODE, int H>
 __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, int b, float* xio) {
   constexpr int D = 64, M = 256;
+  constexpr bool INFER = (MODE == MODE_INFER || MODE == MODE_LAZY);
   constexpr int NCH = 4 / H;                 // 16-column groups per head (head dim 64 / H)
   constexpr float qscale = (H == 1) ? 0.125f : (H == 2 ? 0.17677669529663687f : 0.25f);   // 1 / sqrt(head dim)
   // 4 tiles (69.6 KB) so two workgroups share a CU: K and V persist from the forward into the
@@ -221,13 +247,35 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   STAMP(0);
   // ---- forward ---------------------------------------------------------------------------------------
   float x[16], y[16];
+  float hn[16];                               // the next vode's rows (target of this block's prediction)
+  float gn_lazy[MODE == MODE_LAZY ? 16 : 1], mn_lazy[MODE == MODE_LAZY ? 16 : 1], cn_lazy = 0.f;
   float qkeep[MODE == MODE_CHAIN ? 1 : 16];   // q of the forward, kept for the attention backward
   // gelu'(a) of the MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
   // the backward; the STORE pass writes it to HBM anyway (weight-gradient GEMM operand) and reloads it.
-  float a_keep[MODE == MODE_INFER ? 64 : 1];
+  float a_keep[INFER ? 64 : 1];
   if (MODE == MODE_CHAIN) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = xio[k];
+  } else if (MODE == MODE_LAZY) {
+    // the update of the previous step, applied on the way in: x is this block's INPUT vode, so this workgroup writes its
+    // new value and momentum (new arenas: the old ones are still being read by the block below, whose target it is);
+    // hn, the TARGET vode, is only read -- the block above writes it.  Its updated rows wait in this lane's slot of the
+    // error tensor (written at the end of the forward anyway) instead of 16 registers across the attention.
+    float cx, cn_, c3_;
+    vode_multipliers_wave(p.up, g + 1, g + 2, g + 1, cx, cn_, c3_);   // its loads go out first, the rows' right behind
+    cn_lazy = cn_;
+    float gx[16], mx[16];
+    load_rowT(x, xrow, D, grp);
+    load_rowT(gx, p.Go1 + voff, D, grp);
+    load_rowT(mx, p.Mo1 + voff, D, grp);
+    load_rowT(hn, hnext, D, grp);                     // consumed after the q | k | v tiles (see below): off this
+    load_rowT(gn_lazy, p.Go1 + voff + nl, D, grp);    // workgroup's start-up path, and only live where registers are free
+    load_rowT(mn_lazy, p.Mo1 + voff + nl, D, grp);
+    const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mx[k] = gx[k] * cx + mu * mx[k]; x[k] -= eta * mx[k]; }
+    store_rowT(mx, p.Mn1 + voff, grp);
+    store_rowT(x, p.Hn1 + voff, grp);
   } else {
     load_rowT(x, xrow, D, grp);
   }
@@ -266,6 +314,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
     }
     __syncthreads();   // K, V of all 64 tokens visible
+    if (MODE == MODE_LAZY) {
+      const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) hn[k] -= eta * (gn_lazy[k] * cn_lazy + mu * mn_lazy[k]);
+      store_rowT(hn, p.E2 + (long long)g * nl + rowoff, grp);
+    }
    
     STAMP(2);
     // attention: S[key][q] -> softmax over keys -> O
@@ -303,7 +357,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += x[k];
   }
-  float hn[16];
   {
     float zn[16];
     {
@@ -316,7 +369,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     STAMP(4);
     // the next vode's rows (target of this block's prediction): fetched here so the HBM latency runs
     // under the MLP instead of in front of the error
-    if (MODE != MODE_CHAIN) load_rowT(hn, hnext, D, grp);
+    if (MODE != MODE_CHAIN) load_rowT(hn, MODE == MODE_LAZY ? p.E2 + (long long)g * nl + rowoff : hnext, D, grp);
     // a_mt = LN2(y) W1[mt]^T + b1 ; z += gelu(a_mt) W2[:, mt]^T   (row tile of W1, K-chunk of W2, interleaved)
     f32x4 zacc[4];
     zero4(zacc);
@@ -332,7 +385,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] += b1[k];
       }
-      if (MODE == MODE_INFER) {   // keep gelu'(a) for the backward: it shares the exp2 / rcp with gelu(a)
+      if (INFER) {   // keep gelu'(a) for the backward: it shares the exp2 / rcp with gelu(a)
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
           f32x2 g2, gp2;
@@ -401,7 +454,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       if (mt < 2) SUB(3 + 6 * mt);
       PREFETCH(W1T + mt * 64, M);                           // -> tile 13+2mt: W1^T[:, mt]
       float am[16], dg[16];     // am: gelu'(a)
-      if (MODE == MODE_INFER) {
+      if (INFER) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) am[k] = a_keep[16 * mt + k];
       } else {
@@ -561,7 +614,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     STAMP(12);
     float dxn[16], gm[16], bt[16], xh[17], xv[16], tmp[16];
     unpack(acc, dxn);
-    load_rowT(xv, xrow, D, grp);          // LN1's normalised input is recomputed from x
+    load_rowT(xv, MODE == MODE_LAZY ? p.Hn1 + voff : xrow, D, grp);          // LN1's normalised input is recomputed from x (LAZY: the row this lane stored on the way in)
     load_rowT(gm, pb + PB_LN1G, D, grp);
 #pragma unroll
     for (int k = 0; k < 16; ++k) bt[k] = 0.f;
@@ -996,7 +1049,7 @@ __global__ __launch_bounds__(512) void pc_block_pair_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.L * p.B) {   // edge layers of one image: the first four waves, as in the 4-wave kernel
     if (threadIdx.x >= 256) return;
-    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
+    edge_path<false>(p, lds, (int)blockIdx.x - p.L * p.B);
     return;
   }
   int j = (int)blockIdx.x;
@@ -1009,7 +1062,7 @@ template <int MODE, int H>
 __global__ __launch_bounds__(256, 2) void pc_block_fused_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
-    edge_path(p, lds, (int)blockIdx.x - p.L * p.B);
+    edge_path<MODE == MODE_LAZY>(p, lds, (int)blockIdx.x - p.L * p.B);
     return;
   }
   // XCD-aware order: the hardware deals workgroups round-robin over the 8 XCDs (id % 8), each with its
@@ -1101,10 +1154,15 @@ static int launch_fused_h(const FusedP& p, int L, int store, hipStream_t st) {
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_INFER, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_STORE, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_fused_kernel<MODE_LAZY, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_chain_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_pair_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_pair_lds_bytes()) != hipSuccess) return -1;
   }
   if (L < 0) return 0;   // attribute set-up only
+  if (!store && p.lazy) {
+    hipLaunchKernelGGL((pc_block_fused_kernel<MODE_LAZY, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
+    return 0;
+  }
   if (!store && fused_pair_wanted(L, p.B)) {
     hipLaunchKernelGGL(pc_block_pair_kernel<H>, dim3((L + 1) * p.B), dim3(512), fused_pair_lds_bytes(), st, p);
     return 0;

@@ -8,6 +8,7 @@
 // clipped reconstruction MSE (/root/reference/src/decoder_transformer.py:491-494).
 // All loads/stores are 16 B per lane; reductions are wave shuffles -> LDS -> one f64 atomic per block.
 #include "common.h"
+#include "vode_mult.h"
 
 #define LN_EPS 1e-5f
 
@@ -203,52 +204,7 @@ void launch_patchify(const float* img, float* xp, int B, int F, int C, int Himg,
   else hipLaunchKernelGGL(patchify_kernel, grid, dim3(256), 0, st, img, xp, total, F, C, Himg, Wimg, p, 0);
 }
 
-// ---- vode update ----------------------------------------------------------------------------------
-// per-leaf multipliers: optional per-leaf normalisation, then the global-norm clip over all leaves
-// (mult[nlayers] is the un-frozen sensory leaf's, layer scale included).  One thread, reading the slots from the
-// block's LDS copy (ss: [nlayers][8], se: [sens_n]) -- straight from global memory the layer loop was a chain of
-// nlayers dependent L2 round trips at the head of every block (a third of the kernel at small batches).
-constexpr int MULT_MAX_LAYERS = 65;
-__device__ void stage_multiplier_inputs(const UpdateP& p, double* ss, double* se) {
-  for (int j = threadIdx.x; j < p.nlayers * 8; j += blockDim.x) ss[j] = p.sumsq[j];
-  if (p.sens_e && (int)threadIdx.x < p.sens_n) se[threadIdx.x] = p.sens_e[threadIdx.x];
-}
-__device__ void vode_multipliers(const UpdateP& p, float* mult, const double* ss, const double* se) {
-  double tot = 0.0;
-  for (int l = 0; l < p.nlayers; ++l) {
-    double n2 = 0.0;
-    for (int k = 0; k < 8; ++k) n2 += ss[l * 8 + k];
-    float m = 1.f;
-    if (p.use_grad_norm) {
-      double nrm = sqrt(n2);
-      m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
-      n2 = n2 * (double)m * (double)m;
-    }
-    mult[l] = m;
-    tot += n2;
-  }
-  mult[p.nlayers] = 0.f;
-  if (p.sens_e) {
-    double es = 0.0;
-    for (int k = 0; k < p.sens_n; ++k) es += se[k];
-    double n2 = 2.0 * (double)p.sens_s * (double)p.sens_s * es;
-    float m = 1.f;
-    if (p.use_grad_norm) {
-      double nrm = sqrt(n2);
-      m = (float)((double)p.grad_norm_target / (nrm + 1e-8));
-      n2 = n2 * (double)m * (double)m;
-    }
-    mult[p.nlayers] = m * p.sens_s;
-    tot += n2;
-  }
-  float cm = 1.f;
-  if (p.clip > 0.f) {
-    double gn = sqrt(tot);
-    if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
-  }
-  for (int l = 0; l <= p.nlayers; ++l) mult[l] *= cm;
-}
-
+// ---- vode update (per-leaf multipliers: vode_mult.h) ------------------------------------------------
 __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   __shared__ float mult_sh[MULT_MAX_LAYERS + 1];
   __shared__ double ss_sh[MULT_MAX_LAYERS * 8], se_sh[8];
@@ -276,6 +232,8 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
   if (threadIdx.x == 0) vode_multipliers(p, mult_sh, ss_sh, se_sh);
   __syncthreads();
   const float eta = p.eta[p.t];
+  float* const hdst = p.h_out ? p.h_out : p.h;
+  float* const mdst = p.m_out ? p.m_out : p.m;
   while (i0 < n4) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -286,8 +244,9 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateP p) {
       m[u].x = g[u].x * mul + p.mu * m[u].x; m[u].y = g[u].y * mul + p.mu * m[u].y;
       m[u].z = g[u].z * mul + p.mu * m[u].z; m[u].w = g[u].w * mul + p.mu * m[u].w;
       h[u].x -= eta * m[u].x; h[u].y -= eta * m[u].y; h[u].z -= eta * m[u].z; h[u].w -= eta * m[u].w;
-      *reinterpret_cast<float4*>(p.m + e) = m[u];
-      *reinterpret_cast<float4*>(p.h + e) = h[u];
+      if (p.g_out) *reinterpret_cast<float4*>(p.g_out + e) = g[u];
+      *reinterpret_cast<float4*>(mdst + e) = m[u];
+      *reinterpret_cast<float4*>(hdst + e) = h[u];
     }
     i0 += NS * stride;
     if (i0 < n4) fetch();

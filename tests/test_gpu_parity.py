@@ -233,6 +233,48 @@ def test_fused_pair_kernel_matches_four_wave_kernel_at_B25(H, monkeypatch):
         assert np.abs(a["gw"][k] - b["gw"][k]).max() <= 1e-4 * gmax, k
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 6])
+@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg"])
+def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
+    """D = 64 fused path: inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
+    of step t + 1 as it loads its rows (FusedP::lazy, vodes / momentum / gradients ping-ponging between two arena
+    sets; the last step updates explicitly, back into set 0).  CORA_NO_LAZY=1 launches update_kernel after every step
+    instead.  Same arithmetic, so vodes, final gradients, energies and dE/dW must agree to fp32 rounding -- with the
+    clip firing, with per-leaf gradient normalisation, with regularisers, for odd and even numbers of deferred
+    updates (T - 1), and across two batches (the second replays the captured graph)."""
+    import cora_amd as ca
+    H = {"h1": 1, "h2_gradnorm": 2, "h4_reg": 4}[variant]
+    kw = dict(clip_h=3.0, clip_w=0.5)
+    if variant == "h2_gradnorm":
+        kw.update(use_grad_norm=True, grad_norm_target=2.0)
+    if variant == "h4_reg":
+        kw.update(l1=1e-3, l2=1e-3)
+    case = make_case((3, 32, 32), 4, 64, H, 3, 5, seed=900 + T, **kw)
+    res = []
+    for lazy in (True, False):
+        if lazy:
+            monkeypatch.delenv("CORA_NO_LAZY", raising=False)
+        else:
+            monkeypatch.setenv("CORA_NO_LAZY", "1")
+        model, ow, oh = build_model(case)
+        assert model.kernel_path() == "fused"
+        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(3)]
+        tot, per = ca.step_energies(model, T)
+        res.append(dict(out=outs, tot=tot, per=per, h=[model.vodes[l].h.get() for l in range(5)],
+                        gh=[np.asarray(outs[-1][2][l]) for l in range(5)], gw={k: outs[-1][3][k] for k in model.param_keys()}))
+        model.close()
+    a, b = res
+    assert relerr(a["tot"], b["tot"]) <= 1e-6 and relerr(a["per"], b["per"]) <= 1e-6
+    for oa, ob in zip(a["out"], b["out"]):
+        assert oa[0] == pytest.approx(ob[0], rel=1e-6) and oa[1] == pytest.approx(ob[1], rel=1e-6) and oa[4] == pytest.approx(ob[4], rel=1e-5)
+    for l in range(5):
+        assert relerr(a["h"][l], b["h"][l]) <= 2e-6, l
+        assert relerr(a["gh"][l], b["gh"][l]) <= 2e-5, l
+    gmax = max(np.abs(v).max() for v in b["gw"].values())
+    for k in b["gw"]:
+        assert np.abs(a["gw"][k] - b["gw"][k]).max() <= 2e-5 * gmax, k
+
+
 BF16_TOL = 1e-2
 
 
