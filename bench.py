@@ -424,6 +424,10 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
                 roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None,
                         "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+            if dom == "pc_block_fused" and not os.environ.get("CORA_NO_LAZY") and not os.environ.get("CORA_PAIR"):
+                # in a T-step loop this launch also applies the previous step's momentum-SGD update to
+                # the rows it loads (what used to be the separate, HBM-bound update launch), at unchanged MFMA work
+                roof["note"] = "launch carries the previous step's vode update (no separate update launch)"
             reps = 5  # cora_profile_step repeats the step 5 times
             res["roofline"] = roof
             res["kernel_ms_per_inference_step"] = {k: v["ms"] / reps for k, v in kinds.items()}
@@ -447,17 +451,17 @@ def offline_traffic(roof, cfg_name, B, over):
     if over or B != 200 or roof.get("kernel") != "pc_block_fused":
         return
     # (file, kernel-name prefix) per benchmarked configuration
-    table = {"6block": (("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"), "void pc_block_fused_kernel<0"),
-             "12block": (("r3_pmc_traffic_12block.json", "r2_pmc_traffic_12block.json",), "void pc_block_wide2_kernel")}
+    table = {"6block": (("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"), ("void pc_block_fused_kernel<3", "void pc_block_fused_kernel<0")),
+             "12block": (("r3_pmc_traffic_12block.json", "r2_pmc_traffic_12block.json",), ("void pc_block_wide2_kernel",))}
     if cfg_name not in table:
         return
-    files, prefix = table[cfg_name]
+    files, prefixes = table[cfg_name]
     for fn in files:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
             continue
-        key = next((k for k in tj if k.startswith(prefix)), None)
+        key = next((k for pre in prefixes for k in tj if k.startswith(pre)), None)
         if key and "WRITE_SIZE_per_launch_KB" in tj[key] and "FETCH_SIZE_per_launch_KB" in tj[key]:
             roof["traffic"] = 1024.0 * (2.0 * tj[key]["FETCH_SIZE_per_launch_KB"] + tj[key]["WRITE_SIZE_per_launch_KB"])
             roof["traffic_source"] = f"profiles/{fn} (rocprofv3 PMC, offline)"

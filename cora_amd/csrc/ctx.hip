@@ -602,6 +602,21 @@ int errors_pass(cora_ctx* c, int slot, int store = 0, double* ss = nullptr) {
   return 0;
 }
 
+// A deferred vode update is waiting (cora_ctx::pend): point the launch at the old arenas for its reads and at the other
+// set for what it writes (FusedP::lazy), and flip.
+bool lazy_args(cora_ctx* c, FusedP& f) {
+  if (c->pend < 0) return false;
+  float *Ho = c->Hc(), *Mo = c->Mc(), *Go = c->Gc();
+  c->cur ^= 1;
+  float *Hn = c->Hc(), *Mn = c->Mc(), *Gn = c->Gc();
+  f.lazy = 1;
+  f.H0 = Ho; f.H1 = Ho + c->n0; f.M0o = Mo; f.Mo1 = Mo + c->n0; f.G0o = Go; f.Go1 = Go + c->n0;
+  f.H0n = Hn; f.Hn1 = Hn + c->n0; f.M0n = Mn; f.Mn1 = Mn + c->n0; f.G0 = Gn; f.BP1 = Gn + c->n0;
+  fill_update(c, f.up, c->pend);
+  c->pend = -1;
+  return true;
+}
+
 // first half of inference step t: errors, energies, dE/dh for every un-frozen vode with layer
 // scaling, and the per-vode sums of squares of this shard (row t of c->sumsq)
 int infer_grad_step(cora_ctx* c, int t) {
@@ -615,17 +630,7 @@ int infer_grad_step(cora_ctx* c, int t) {
     FusedP f;
     fill_fused(c, f, nullptr, ss);
     f.esens = es + (long long)(L + 2) * 8;
-    const bool lazy = c->pend >= 0;
-    if (lazy) {   // the update of step `pend` rides in this launch: old arenas in, the other set out
-      float *Ho = c->Hc(), *Mo = c->Mc(), *Go = c->Gc();
-      c->cur ^= 1;
-      float *Hn = c->Hc(), *Mn = c->Mc(), *Gn = c->Gc();
-      f.lazy = 1;
-      f.H0 = Ho; f.H1 = Ho + c->n0; f.M0o = Mo; f.Mo1 = Mo + c->n0; f.G0o = Go; f.Go1 = Go + c->n0;
-      f.H0n = Hn; f.Hn1 = Hn + c->n0; f.M0n = Mn; f.Mn1 = Mn + c->n0; f.G0 = Gn; f.BP1 = Gn + c->n0;
-      fill_update(c, f.up, c->pend);
-      c->pend = -1;
-    }
+    const bool lazy = lazy_args(c, f);   // the update of step `pend` rides in this launch
     {
       double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
       KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0));
@@ -645,12 +650,13 @@ int infer_grad_step(cora_ctx* c, int t) {
     FusedP f;
     fill_fused(c, f, nullptr, ss);
     f.esens = es + (long long)(L + 2) * 8;
+    const bool lazy = lazy_args(c, f);   // wide2 only (lazy_ok): the update of step `pend` rides in this launch
     {
-      KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl);
+      KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0));
       if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);
-    v.bp = vode_ptr(c, c->Gs, 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hs, 1); v.g = vode_ptr(c, c->Gs, 1);
+    v.bp = vode_ptr(c, c->Gc(), 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hc(), 1); v.g = vode_ptr(c, c->Gc(), 1);
     v.gscale = c->gscale; v.nl = c->nl; v.nlay = L + 1; v.l1 = c->cfg.l1; v.l2 = c->cfg.l2;
     v.sumsq = ss + 8; v.esum = es + 8;
     KScope s2(c, K_GRADFIN, 0, 12.0 * (L + 1) * c->nl);
@@ -710,7 +716,7 @@ void fill_update(cora_ctx* c, UpdateP& u, int t) {
 }
 int infer_update_step(cora_ctx* c, int t) {
   const int L = c->L;
-  if (c->lazy_ok && t + 1 < c->lazy_T && !c->sens_live) {   // D = 64 fused path: the next inference launch applies it
+  if (c->lazy_ok && t + 1 < c->lazy_T && !c->sens_live) {   // D = 64 fused path and wide2: the next inference launch applies it
     c->pend = t;
     return 0;
   }
@@ -969,7 +975,7 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
   }
   DA(c->Hs, c->nV); DA(c->Ms, c->nV); DA(c->Gs, c->nV);
   // second arena set of the deferred vode update (see cora_ctx::Hs2); the experimental 8-wave kernel has no such form
-  if (c->fused && !getenv("CORA_NO_LAZY") && !fused_pair_wanted((int)L, c->B)) {
+  if ((c->fused || c->fusedw2) && !getenv("CORA_NO_LAZY") && !fused_pair_wanted((int)L, c->B)) {
     DA(c->Hs2, c->nV); DA(c->Ms2, c->nV); DA(c->Gs2, c->nV);
     c->lazy_ok = true;
   }

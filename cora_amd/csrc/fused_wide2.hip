@@ -186,7 +186,10 @@ __device__ __forceinline__ void store_slice(const float* f, float* base, int grp
   _Pragma("unroll") for (int j_ = 0; j_ < NQ; ++j_) STAGE((K0) + j_, XF, (ACCD) + NOT * j_);
 
 
-template <int NCT, int H>
+// LAZY (FusedP::lazy): the rows come in with the previous step's vode update applied -- the input vode's new
+// value and momentum are written to the new arenas, the target's updated rows wait in this workgroup's slot of the error
+// tensor until the forward needs them.
+template <int NCT, int H, bool LAZY>
 __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, int g, int b) {
   constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
   constexpr int NOT = 2, TR = 32;                 // weight tile: 32 output rows x D inputs
@@ -218,6 +221,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   const long long voff = (long long)g * nl + rowoff;
   const float* xrow = p.H1 + voff;
   const float* hnext = p.H1 + voff + nl;
+  const float* xcur = LAZY ? p.Hn1 + voff : xrow;                          // where the later reloads of x come from
+  const float* hncur = LAZY ? p.E2 + (long long)g * nl + rowoff : hnext;   // ... and the target rows
   const long long srow_g = ((long long)g * p.B + b) * 64 + 16 * w + i;
   float* st_p = p.S_stash + srow_g * (H * 64 + 3 * D);   // per token row: P (64 keys per head) | q | k | v
   float* st_q = st_p + H * 64;
@@ -291,6 +296,24 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
       {
         float x[R], gm[R], bt[R], xh[R + 1];
         load_row<NCT>(x, xrow, grp);
+        if (LAZY) {
+          float cx, cn, c3;
+          vode_multipliers_wave(p.up, g + 1, g + 2, g + 1, cx, cn, c3);
+          const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+          {
+            float hn[R], gn[R], mn[R];
+            load_row<NCT>(hn, hnext, grp); load_row<NCT>(gn, p.Go1 + voff + nl, grp); load_row<NCT>(mn, p.Mo1 + voff + nl, grp);
+#pragma unroll
+            for (int k = 0; k < R; ++k) hn[k] -= eta * (gn[k] * cn + mu * mn[k]);
+            store_row<NCT>(hn, p.E2 + (long long)g * nl + rowoff, grp);
+          }
+          float* gx = gm; float* mx = bt;      // (the LayerNorm parameters are loaded after)
+          load_row<NCT>(gx, p.Go1 + voff, grp); load_row<NCT>(mx, p.Mo1 + voff, grp);
+#pragma unroll
+          for (int k = 0; k < R; ++k) { mx[k] = gx[k] * cx + mu * mx[k]; x[k] -= eta * mx[k]; }
+          store_row<NCT>(mx, p.Mn1 + voff, grp);
+          store_row<NCT>(x, p.Hn1 + voff, grp);
+        }
         load_row<NCT>(gm, ln1g, grp);
         load_row<NCT>(bt, ln1b, grp);
         ln_row<NCT>(x, gm, bt, xh, xin);
@@ -345,7 +368,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     GEMM_D(3 * NQ, of, y)
     {
       float x[R];
-      load_row<NCT>(x, xrow, grp);        // x again (L2): not kept live across the attention
+      load_row<NCT>(x, xcur, grp);        // x again (L2): not kept live across the attention
 #pragma unroll
       for (int k = 0; k < R; ++k) y[k] += x[k];
     }
@@ -380,8 +403,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         store_row<NCT>(b1, st_a + mt * D, grp);     // gelu'(a) waits in the stash for the backward
       }
       if (mt == 3) {      // x again and the next vode's rows: their latency runs under the last four tiles
-        load_row<NCT>(r, xrow, grp);
-        load_row<NCT>(zn, hnext, grp);
+        load_row<NCT>(r, xcur, grp);
+        load_row<NCT>(zn, hncur, grp);
       }
       GEMM_D_ACC(5 * NQ + 2 * NQ * mt, am, zacc)
     }
@@ -510,7 +533,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     GEMM_D_ACC(23 * NQ, dy, xacc)
     W2STAMP(12);
     float dxn[R], gm[R], xh[R + 1], tmp[R], x[R];
-    load_row<NCT>(x, xrow, grp);                 // LN1's normalised input is recomputed from x
+    load_row<NCT>(x, xcur, grp);                 // LN1's normalised input is recomputed from x
     unpack_at<NCT>(xacc, dxn, 0);
     load_row<NCT>(gm, pb + PB_LN1G, grp);
     ln_row<NCT>(x, gm, nullptr, xh, tmp);
@@ -687,18 +710,18 @@ __global__ __launch_bounds__(256, 1) void pc_chain_wide2_kernel(FusedP p, const 
   wide2_chain_body<NCT, H>(p, lds, (int)blockIdx.x, xin, xout, stride);
 }
 
-template <int NCT, int H>
+template <int NCT, int H, bool LAZY>
 __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.L * p.B) {   // the last B workgroups do the two edge layers of one image each
-    edge_path_wide<NCT>(p, lds, (int)blockIdx.x - p.L * p.B);
+    edge_path_wide<NCT, LAZY>(p, lds, (int)blockIdx.x - p.L * p.B);
     return;
   }
   // XCD-aware order (see fused_block.hip): XCD x gets a contiguous eighth of the (block, image) list
   int j = (int)blockIdx.x;
   const int n = p.L * p.B;
   if ((n & 7) == 0) j = (j & 7) * (n >> 3) + (j >> 3);
-  wide2_block_body<NCT, H>(p, lds, j / p.B, j % p.B);
+  wide2_block_body<NCT, H, LAZY>(p, lds, j / p.B, j % p.B);
 }
 
 size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
@@ -710,9 +733,11 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
   constexpr int NCT = 8, H = 4, D = 128, M = 512;
   const size_t sm = (size_t)(2 * 32 * (D + 4) + 4 * 64 * 36 + 2 * H * 64 + M + 4 * D) * sizeof(float);
   if (first_use_on_device(attr)) {
-    if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
   }
-  hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  if (p.lazy) hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H, true>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
+  else hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H, false>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
 

@@ -3,6 +3,7 @@
 // rows, MFMA tile products, opaque LDS pointers.  gfx950 only.
 #pragma once
 #include "common.h"
+#include "vode_mult.h"
 
 namespace {
 
@@ -293,7 +294,7 @@ __device__ __forceinline__ void edge_copy_to_lds(float* dst, const float* src, i
     *reinterpret_cast<float4*>(&dst[rr * ldt + 4 * c4]) = *reinterpret_cast<const float4*>(src + (long long)rr * cols + 4 * c4);
   }
 }
-template <int NCT>
+template <int NCT, bool LAZY = false>
 __device__ __forceinline__ void edge_path_wide(const FusedP& p, float* lds, int b) {
   constexpr int D = 16 * NCT, P = 48, LP = P + 4, LDD = D + 4, R = 4 * NCT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -305,10 +306,24 @@ __device__ __forceinline__ void edge_path_wide(const FusedP& p, float* lds, int 
   edge_copy_to_lds(sA, p.W + p.oWp, D, P, LP, tid);
   edge_copy_to_lds(sB, p.WT + p.tWp, P, D, LDD, tid);
   float e1[R];
+  float c0 = 0.f, c1 = 0.f, cl = 0.f;     // LAZY (FusedP::lazy): multipliers of the update this launch applies to vodes 0, 1, L+1
+  if (LAZY) vode_multipliers_wave(p.up, 0, 1, p.L + 1, c0, c1, cl);
   {
     float h0[12];
     load_row<3>(h0, p.H0 + tok * P, grp);
     load_row<NCT>(e1, p.H1 + tok * D, grp);                  // h_1
+    if (LAZY) {   // vode 0 is this workgroup's input (it writes the new value and momentum), vode 1 only its target
+      const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+      float g0[12], m0[12];
+      load_row<3>(g0, p.G0o + tok * P, grp); load_row<3>(m0, p.M0o + tok * P, grp);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { m0[k] = g0[k] * c0 + mu * m0[k]; h0[k] -= eta * m0[k]; }
+      store_row<3>(h0, p.H0n + tok * P, grp); store_row<3>(m0, p.M0n + tok * P, grp);
+      float g1[R], m1[R];
+      load_row<NCT>(g1, p.Go1 + tok * D, grp); load_row<NCT>(m1, p.Mo1 + tok * D, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) e1[k] -= eta * (g1[k] * c1 + mu * m1[k]);
+    }
     __syncthreads();
     f32x4 acc[NCT];
     zero_acc<NCT>(acc);
@@ -343,6 +358,15 @@ __device__ __forceinline__ void edge_path_wide(const FusedP& p, float* lds, int 
     load_row<NCT>(hl, p.H1 + (long long)p.L * nl + tok * D, grp);
     load_row<3>(xp, p.XP + tok * P, grp);
     load_row<3>(bo, p.W + p.obout, grp);
+    if (LAZY) {   // vode L+1: input of the output projection, so written here
+      const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+      const long long oL = (long long)p.L * nl + tok * D;
+      float gl[R], ml[R];
+      load_row<NCT>(gl, p.Go1 + oL, grp); load_row<NCT>(ml, p.Mo1 + oL, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) { ml[k] = gl[k] * cl + mu * ml[k]; hl[k] -= eta * ml[k]; }
+      store_row<NCT>(hl, p.Hn1 + oL, grp); store_row<NCT>(ml, p.Mn1 + oL, grp);
+    }
     __syncthreads();
     f32x4 acc[3];
     zero_acc<3>(acc);

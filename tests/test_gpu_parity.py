@@ -234,22 +234,22 @@ def test_fused_pair_kernel_matches_four_wave_kernel_at_B25(H, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
-@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg"])
+@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg"])
 def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
-    """D = 64 fused path: inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
+    """D = 64 fused path and the D = 128 / heads-of-32 kernel (wide2): inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
     of step t + 1 as it loads its rows (FusedP::lazy, vodes / momentum / gradients ping-ponging between two arena
     sets; the last step updates explicitly, back into set 0).  CORA_NO_LAZY=1 launches update_kernel after every step
     instead.  Same arithmetic, so vodes, final gradients, energies and dE/dW must agree to fp32 rounding -- with the
     clip firing, with per-leaf gradient normalisation, with regularisers, for odd and even numbers of deferred
     updates (T - 1), and across two batches (the second replays the captured graph)."""
     import cora_amd as ca
-    H = {"h1": 1, "h2_gradnorm": 2, "h4_reg": 4}[variant]
+    D, H = {"h1": (64, 1), "h2_gradnorm": (64, 2), "h4_reg": (64, 4), "wide2": (128, 4), "wide2_gradnorm_reg": (128, 4)}[variant]
     kw = dict(clip_h=3.0, clip_w=0.5)
-    if variant == "h2_gradnorm":
+    if "gradnorm" in variant:
         kw.update(use_grad_norm=True, grad_norm_target=2.0)
-    if variant == "h4_reg":
+    if "reg" in variant:
         kw.update(l1=1e-3, l2=1e-3)
-    case = make_case((3, 32, 32), 4, 64, H, 3, 5, seed=900 + T, **kw)
+    case = make_case((3, 32, 32), 4, D, H, 3, 5, seed=900 + T, **kw)
     res = []
     for lazy in (True, False):
         if lazy:
@@ -257,7 +257,7 @@ def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
         else:
             monkeypatch.setenv("CORA_NO_LAZY", "1")
         model, ow, oh = build_model(case)
-        assert model.kernel_path() == "fused"
+        assert model.kernel_path() == ("fused" if D == 64 else "fused-wide")
         outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(3)]
         tot, per = ca.step_energies(model, T)
         res.append(dict(out=outs, tot=tot, per=per, h=[model.vodes[l].h.get() for l in range(5)],
