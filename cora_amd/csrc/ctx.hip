@@ -237,7 +237,10 @@ int dalloc(cora_ctx* c, float** p, long long n) {
 int flush_lazy_update(cora_ctx* c);
 void fill_update(cora_ctx* c, UpdateP& u, int t);
 int settle_pending(cora_ctx* c) {
-  if (int rc_ = flush_lazy_update(c)) return rc_;   // a split-API loop abandoned between cora_infer_update and the next cora_infer_grad
+  if (c->pend >= 0) {   // a split-API loop abandoned between cora_infer_update and the next cora_infer_grad
+    HCHECK(hipSetDevice(c->device));
+    if (int rc_ = flush_lazy_update(c)) return rc_;
+  }
   c->lazy_T = 0;
   if (!c->infer_pending) return 0;
   HCHECK(hipSetDevice(c->device));

@@ -160,7 +160,10 @@ int cora_step_ipc(cora_ctx* ctx, const float* x, int x_on_device, int T, const f
  *              cora_infer_sumsq(t, row, n, 1); cora_infer_update(t);
  *   cora_infer_end(out)         -- out->final_h_energy is this shard's part
  * row = (L+2)*8 doubles (8 partial sums per vode).  Eager launches, one host round trip per step:
- * the captured single-graph cora_infer with the per-shard norm stays the fast path. */
+ * the captured single-graph cora_infer with the per-shard norm stays the fast path.
+ * On the D = 64 and D = 128 / heads-of-32 fused paths cora_infer_update(t) for t < T - 1 launches nothing: the
+ * step is applied by cora_infer_grad(t + 1) as it loads its rows (so row t must be final when that is called).
+ * cora_infer_end -- or any other entry point, if the loop is cut short -- brings the vodes up to date. */
 int cora_infer_begin(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h);
 int cora_infer_grad(cora_ctx* ctx, int t);
 int cora_infer_sumsq(cora_ctx* ctx, int t, double* host_row, size_t n_doubles, int set);

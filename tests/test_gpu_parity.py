@@ -275,6 +275,38 @@ def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
         assert np.abs(a["gw"][k] - b["gw"][k]).max() <= 2e-5 * gmax, k
 
 
+def test_split_loop_cut_short_still_applies_the_deferred_update(monkeypatch):
+    """cora_infer_begin / _grad / _update driven from the host and abandoned after two steps of four: the update of
+    step 1 is still waiting for a launch that never comes (D = 64 path), so the next entry point that looks at the
+    vodes (here cora_get_vode) has to apply it.  Against the same calls with CORA_NO_LAZY=1."""
+    import ctypes as C
+    import cora_amd as ca
+    from cora_amd import _lib
+    case = make_case((3, 32, 32), 4, 64, 2, 3, 4, seed=5, clip_h=3.0, clip_w=0.5)
+    x = np.ascontiguousarray(case["x"], dtype=np.float32)
+    eta = np.full(4, 0.095, dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.c_void_p)
+    res = []
+    for lazy in (True, False):
+        if lazy:
+            monkeypatch.delenv("CORA_NO_LAZY", raising=False)
+        else:
+            monkeypatch.setenv("CORA_NO_LAZY", "1")
+        model, ow, oh = build_model(case)
+        ca.train_on_batch(3, case["x"], model=model, optim_w=ow, optim_h=oh)     # vodes initialised, one learning step
+        lib, ctx = _lib.load(), model._ctx
+        _lib.check(lib.cora_infer_begin(ctx, fp(x), 0, 4, fp(eta)), ctx)
+        for t in range(2):
+            _lib.check(lib.cora_infer_grad(ctx, t), ctx)
+            _lib.check(lib.cora_infer_update(ctx, t), ctx)
+        res.append([model.vodes[l].h.get() for l in range(5)])
+        ca.train_on_batch(3, case["x"], model=model, optim_w=ow, optim_h=oh)     # and the ctx is usable afterwards
+        res[-1] += [model.vodes[l].h.get() for l in range(5)]
+        model.close()
+    for a, b in zip(*res):
+        assert relerr(a, b) <= 2e-6
+
+
 BF16_TOL = 1e-2
 
 
