@@ -199,15 +199,21 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   const float* WqkvT = p.WT + p.tWqkv + (long long)g * D * 3 * D;  // [D][3D]
   const float* ln1g = p.W + p.oLn1g + (long long)g * D;
   const float* ln1b = p.W + p.oLn1b + (long long)g * D;
-  const float* ln2g = p.W + p.oLn2g + (long long)g * D;
-  const float* ln2b = p.W + p.oLn2b + (long long)g * D;
+  // (MODE_LAZY) the clip multipliers' sums of squares: this wave's first load, so that waiting for it waits for nothing else
+  double ss_first = 0.0;
+  float eta_lazy = 0.f;      // ... and the step size: loaded behind the rows, its wait would wait for all of them
+  if (MODE == MODE_LAZY) { ss_first = vode_multipliers_first_load(p.up); eta_lazy = p.up.eta[p.up.t]; }
+  __builtin_amdgcn_sched_barrier(0);
+  // the parameter block: loaded here, written to LDS just before the first tile barrier -- written at once it put a
+  // full memory latency in front of everything else the first two waves issue
+  float4 pbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 128) {
-    const float* src = tid < 64 ? p.W + p.ob1 + (long long)g * M + 4 * tid
-                     : tid < 80 ? ln2g + 4 * (tid - 64)
-                     : tid < 96 ? ln2b + 4 * (tid - 80)
-                     : tid < 112 ? p.W + p.ob2 + (long long)g * D + 4 * (tid - 96)
-                                 : ln1g + 4 * (tid - 112);
-    *reinterpret_cast<float4*>(pb + 4 * tid) = *reinterpret_cast<const float4*>(src);   // visible after the first tile barrier
+    const long long off = tid < 64 ? (long long)p.ob1 + (long long)g * M + 4 * tid
+                        : tid < 80 ? (long long)p.oLn2g + (long long)g * D + 4 * (tid - 64)
+                        : tid < 96 ? (long long)p.oLn2b + (long long)g * D + 4 * (tid - 80)
+                        : tid < 112 ? (long long)p.ob2 + (long long)g * D + 4 * (tid - 96)
+                                    : (long long)p.oLn1g + (long long)g * D + 4 * (tid - 112);
+    pbv = *reinterpret_cast<const float4*>(p.W + off);
   }
 
   // ---- weight tile pipeline: global -> registers (prefetched one tile ahead) -> LDS (double buffered)
@@ -249,6 +255,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   float x[16], y[16];
   float hn[16];                               // the next vode's rows (target of this block's prediction)
   float gn_lazy[MODE == MODE_LAZY ? 16 : 1], mn_lazy[MODE == MODE_LAZY ? 16 : 1], cn_lazy = 0.f;
+  float gm1[16], bt1[16];                     // LayerNorm-1 gamma / beta
   float qkeep[MODE == MODE_CHAIN ? 1 : 16];   // q of the forward, kept for the attention backward
   // gelu'(a) of the MLP pre-activation a (64 values per lane): the inference step has the registers to keep it for
   // the backward; the STORE pass writes it to HBM anyway (weight-gradient GEMM operand) and reloads it.
@@ -261,9 +268,6 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     // new value and momentum (new arenas: the old ones are still being read by the block below, whose target it is);
     // hn, the TARGET vode, is only read -- the block above writes it.  Its updated rows wait in this lane's slot of the
     // error tensor (written at the end of the forward anyway) instead of 16 registers across the attention.
-    float cx, cn_, c3_;
-    vode_multipliers_wave(p.up, g + 1, g + 2, g + 1, cx, cn_, c3_);   // its loads go out first, the rows' right behind
-    cn_lazy = cn_;
     float gx[16], mx[16];
     load_rowT(x, xrow, D, grp);
     load_rowT(gx, p.Go1 + voff, D, grp);
@@ -271,7 +275,13 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     load_rowT(hn, hnext, D, grp);                     // consumed after the q | k | v tiles (see below): off this
     load_rowT(gn_lazy, p.Go1 + voff + nl, D, grp);    // workgroup's start-up path, and only live where registers are free
     load_rowT(mn_lazy, p.Mo1 + voff + nl, D, grp);
-    const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+    load_rowT(gm1, ln1g, D, grp);                     // LayerNorm-1 parameters: behind the update they would cost a latency of their own
+    load_rowT(bt1, ln1b, D, grp);
+    __builtin_amdgcn_sched_barrier(0);                // everything above is in flight while the multipliers are worked out
+    float cx, cn_, c3_;
+    vode_multipliers_wave(p.up, g + 1, g + 2, g + 1, cx, cn_, c3_, ss_first);
+    cn_lazy = cn_;
+    const float eta = eta_lazy, mu = p.up.mu;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { mx[k] = gx[k] * cx + mu * mx[k]; x[k] -= eta * mx[k]; }
     store_rowT(mx, p.Mn1 + voff, grp);
@@ -282,14 +292,17 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   {
     float xin[16];
     {
-      float gm[16], bt[16], xh[17];
-      load_rowT(gm, ln1g, D, grp);
-      load_rowT(bt, ln1b, D, grp);
-      ln_rowT(x, gm, bt, xh, xin);
+      float xh[17];
+      if (MODE != MODE_LAZY) {
+        load_rowT(gm1, ln1g, D, grp);
+        load_rowT(bt1, ln1b, D, grp);
+      }
+      ln_rowT(x, gm1, bt1, xh, xin);
       if (MODE == MODE_STORE) store_rowT(xin, p.S_xn1 + srow_g * D, grp);
     }
     STAMP(1);
     float qf[16];
+    if (tid < 128) *reinterpret_cast<float4*>(pb + 4 * tid) = pbv;   // visible after the first tile barrier
     {  // q, k, v = LN1(x) Wq^T, Wk^T, Wv^T
       PUBLISH(0, t); PREFETCH(Wqkv + 64 * D, D);    // -> tile 1: Wk
      
@@ -315,7 +328,7 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
     }
     __syncthreads();   // K, V of all 64 tokens visible
     if (MODE == MODE_LAZY) {
-      const float eta = p.up.eta[p.up.t], mu = p.up.mu;
+      const float eta = eta_lazy, mu = p.up.mu;
 #pragma unroll
       for (int k = 0; k < 16; ++k) hn[k] -= eta * (gn_lazy[k] * cn_lazy + mu * mn_lazy[k]);
       store_rowT(hn, p.E2 + (long long)g * nl + rowoff, grp);

@@ -57,13 +57,20 @@ __device__ inline void vode_multipliers(const UpdateP& p, float* mult, const dou
 // For the kernels that apply the update on the way in (FusedP::lazy): there the staged form cost two barriers and a
 // serial thread at the head of every workgroup.  No sensory leaf (those launches are excluded when it is un-frozen).
 // Sums run as trees here and serially in vode_multipliers: the doubles may differ in the last bit.
-__device__ inline void vode_multipliers_wave(const UpdateP& p, int la, int lb, int lc, float& ca, float& cb, float& cc) {
+// first0: the caller's own early load of chunk 0 (vode_multipliers_first_load), so that this wave's wait for it does not
+// also wait for every row load issued in between (vector memory returns in order)
+__device__ inline double vode_multipliers_first_load(const UpdateP& p) {
+  const int lane = threadIdx.x & 63, l = lane >> 3;
+  return (l < p.nlayers) ? p.sumsq[l * 8 + (lane & 7)] : 0.0;
+}
+__device__ inline void vode_multipliers_wave(const UpdateP& p, int la, int lb, int lc, float& ca, float& cb, float& cc, double first0) {
   const int lane = threadIdx.x & 63;
   double tot = 0.0;
   float ma = 1.f, mb = 1.f, mc = 1.f;
   for (int l0 = 0; l0 < p.nlayers; l0 += 8) {
     const int l = l0 + (lane >> 3);
-    double v = (l < p.nlayers) ? p.sumsq[l * 8 + (lane & 7)] : 0.0;
+    double v = first0;
+    if (l0 > 0) v = (l < p.nlayers) ? p.sumsq[l * 8 + (lane & 7)] : 0.0;
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);   // n2 of layer l in its 8 lanes
     float m = 1.f;
     if (p.use_grad_norm) {
@@ -84,4 +91,7 @@ __device__ inline void vode_multipliers_wave(const UpdateP& p, int la, int lb, i
     if (!(gn < (double)p.clip)) cm = (float)((double)p.clip / gn);
   }
   ca = ma * cm; cb = mb * cm; cc = mc * cm;
+}
+__device__ inline void vode_multipliers_wave(const UpdateP& p, int la, int lb, int lc, float& ca, float& cb, float& cc) {
+  vode_multipliers_wave(p, la, lb, lc, ca, cb, cc, vode_multipliers_first_load(p));
 }
