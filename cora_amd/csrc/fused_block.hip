@@ -266,15 +266,15 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
   } else if (MODE == MODE_LAZY) {
     // the update of the previous step, applied on the way in: x is this block's INPUT vode, so this workgroup writes its
     // new value and momentum (new arenas: the old ones are still being read by the block below, whose target it is);
-    // hn, the TARGET vode, is only read -- the block above writes it.  Its updated rows wait in this lane's slot of the
-    // error tensor (written at the end of the forward anyway) instead of 16 registers across the attention.
+    // hn, the TARGET vode, is only read -- the block above writes it.  Its three loads go out behind the v tile and are
+    // consumed after the attention (swept: with the input rows at the head of the workgroup -1.5 %, any earlier point in
+    // between proportionally; later -- at the MLP, where the plain kernel loads hn -- the three rows spill), and the
+    // updated rows wait in this lane's slot of the error tensor (written at the end of the forward anyway) instead of
+    // 16 registers across the MLP's neighbours.
     float gx[16], mx[16];
     load_rowT(x, xrow, D, grp);
     load_rowT(gx, p.Go1 + voff, D, grp);
     load_rowT(mx, p.Mo1 + voff, D, grp);
-    load_rowT(hn, hnext, D, grp);                     // consumed after the q | k | v tiles (see below): off this
-    load_rowT(gn_lazy, p.Go1 + voff + nl, D, grp);    // workgroup's start-up path, and only live where registers are free
-    load_rowT(mn_lazy, p.Mo1 + voff + nl, D, grp);
     load_rowT(gm1, ln1g, D, grp);                     // LayerNorm-1 parameters: behind the update they would cost a latency of their own
     load_rowT(bt1, ln1b, D, grp);
     __builtin_amdgcn_sched_barrier(0);                // everything above is in flight while the multipliers are worked out
@@ -323,16 +323,15 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
       PUBLISH(0, t); PREFETCH(Wo, D);               // -> tile 3: Wo
      
       zero4(acc); gemm_tile(t, xin, acc, i, grp); unpack(acc, kf);
+      if (MODE == MODE_LAZY) {   // the target vode's rows, gradient and momentum (see the head of the function)
+        load_rowT(hn, hnext, D, grp);
+        load_rowT(gn_lazy, p.Go1 + voff + nl, D, grp);
+        load_rowT(mn_lazy, p.Mo1 + voff + nl, D, grp);
+      }
      
       store_rowT(kf, &bufV[(16 * w + i) * LD], grp);
     }
     __syncthreads();   // K, V of all 64 tokens visible
-    if (MODE == MODE_LAZY) {
-      const float eta = eta_lazy, mu = p.up.mu;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) hn[k] -= eta * (gn_lazy[k] * cn_lazy + mu * mn_lazy[k]);
-      store_rowT(hn, p.E2 + (long long)g * nl + rowoff, grp);
-    }
    
     STAMP(2);
     // attention: S[key][q] -> softmax over keys -> O
@@ -364,6 +363,12 @@ __device__ __forceinline__ void block_body(const FusedP& p, float* lds, int g, i
         for (int reg = 0; reg < 4; ++reg) of[4 * (NCH * h + c) + reg] = oa[c][reg];
     }
     if (MODE == MODE_STORE) store_rowT(of, p.S_att + srow_g * D, grp);
+    if (MODE == MODE_LAZY) {
+      const float eta = eta_lazy, mu = p.up.mu;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) hn[k] -= eta * (gn_lazy[k] * cn_lazy + mu * mn_lazy[k]);
+      store_rowT(hn, p.E2 + (long long)g * nl + rowoff, grp);
+    }
     STAMP(3);
     PUBLISH(1, t); PREFETCH(W1, D);   // Wo; -> tile 4: W1[0]
     zero4(acc); gemm_tile(t, of, acc, i, grp); unpack(acc, y);
