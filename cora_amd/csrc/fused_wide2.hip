@@ -289,6 +289,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
 
   // ---- forward ---------------------------------------------------------------------------------------
   float y[R];
+  float cn_lazy = 0.f, eta_lazy = 0.f;    // LAZY: multiplier of the target vode's update and the step size
   {
     float q[R], kk[R], v[R];
     {
@@ -300,13 +301,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
           float cx, cn, c3;
           vode_multipliers_wave(p.up, g + 1, g + 2, g + 1, cx, cn, c3);
           const float eta = p.up.eta[p.up.t], mu = p.up.mu;
-          {
-            float hn[R], gn[R], mn[R];
-            load_row<NCT>(hn, hnext, grp); load_row<NCT>(gn, p.Go1 + voff + nl, grp); load_row<NCT>(mn, p.Mo1 + voff + nl, grp);
-#pragma unroll
-            for (int k = 0; k < R; ++k) hn[k] -= eta * (gn[k] * cn + mu * mn[k]);
-            store_row<NCT>(hn, p.E2 + (long long)g * nl + rowoff, grp);
-          }
+          cn_lazy = cn; eta_lazy = eta;
           float* gx = gm; float* mx = bt;      // (the LayerNorm parameters are loaded after)
           load_row<NCT>(gx, p.Go1 + voff, grp); load_row<NCT>(mx, p.Mo1 + voff, grp);
 #pragma unroll
@@ -364,6 +359,15 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
       }
     }
     W2STAMP(3);
+    if (LAZY) {   // the target vode's rows with the deferred update applied, parked in this workgroup's slot of the error
+                  // tensor until the end of the MLP (here q, k, v are dead and only `of` is live)
+      const float mu = p.up.mu;
+      float hn[R], gn[R], mn[R];
+      load_row<NCT>(hn, hnext, grp); load_row<NCT>(gn, p.Go1 + voff + nl, grp); load_row<NCT>(mn, p.Mo1 + voff + nl, grp);
+#pragma unroll
+      for (int k = 0; k < R; ++k) hn[k] -= eta_lazy * (gn[k] * cn_lazy + mu * mn[k]);
+      store_row<NCT>(hn, p.E2 + (long long)g * nl + rowoff, grp);
+    }
     // y = x + att Wo^T
     GEMM_D(3 * NQ, of, y)
     {
