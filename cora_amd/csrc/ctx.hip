@@ -26,7 +26,7 @@ enum Kind { K_GEMM_NT = 0, K_GEMM_NN, K_GEMM_TN, K_ATTN_FWD, K_ATTN_BWD, K_LN_FW
 const char* kKindNames[K_COUNT] = {"gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd",
                                    "ln_fwd", "ln_bwd", "vode_update", "other", "pc_block_fused", "vode_grad", "pc_rows_fused"};
 
-struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; int n; };   // n: launches between the two events (burst)
 
 // RCCL is bound at run time (dlopen on the first cora_comm_* call): the one-GPU path never loads it.
 struct RcclApi {
@@ -188,6 +188,7 @@ struct cora_ctx {
 
   // profiling
   bool prof = false;
+  int prof_burst = 1;   // cora_profile_step: the block kernel is timed as a burst of identical back-to-back launches
   std::vector<ProfRec> recs;
 
   std::vector<void*> allocs;
@@ -212,9 +213,9 @@ namespace {
 
 struct KScope {
   cora_ctx* c; bool on;
-  KScope(cora_ctx* c_, int kind, double flops, double bytes) : c(c_), on(c_->prof) {
+  KScope(cora_ctx* c_, int kind, double flops, double bytes, int n = 1) : c(c_), on(c_->prof) {
     if (!on) return;
-    ProfRec r; r.kind = kind; r.flops = flops; r.bytes = bytes;
+    ProfRec r; r.kind = kind; r.flops = flops; r.bytes = bytes; r.n = n;
     hipEventCreate(&r.e0); hipEventCreate(&r.e1);
     hipEventRecord(r.e0, c->st);
     c->recs.push_back(r);
@@ -636,8 +637,13 @@ int infer_grad_step(cora_ctx* c, int t) {
     const bool lazy = lazy_args(c, f);   // the update of step `pend` rides in this launch
     {
       double fl = block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D;
-      KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0));
-      if (launch_fused_block(f, L, 0, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
+      // profiling: a burst of identical launches under one event pair (the launch is idempotent: it reads the vodes and
+      // -- with a deferred update -- writes the OTHER arena set), so the figure is the back-to-back duration a graph
+      // replay sees, without the event packets and the idle gap of a single bracketed eager launch
+      const int nb = c->prof ? c->prof_burst : 1;
+      KScope s(c, K_FUSED, fl, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0), nb);
+      for (int i = 0; i < nb; ++i)
+        if (launch_fused_block(f, L, 0, c->st)) FAIL(-3, "fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);
     v.bp = vode_ptr(c, c->Gc(), 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hc(), 1); v.g = vode_ptr(c, c->Gc(), 1);
@@ -655,8 +661,10 @@ int infer_grad_step(cora_ctx* c, int t) {
     f.esens = es + (long long)(L + 2) * 8;
     const bool lazy = lazy_args(c, f);   // wide2 only (lazy_ok): the update of step `pend` rides in this launch
     {
-      KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0));
-      if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
+      const int nb = c->prof ? c->prof_burst : 1;   // burst under one event pair, as on the D = 64 path
+      KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0), nb);
+      for (int i = 0; i < nb; ++i)
+        if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);
     v.bp = vode_ptr(c, c->Gc(), 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hc(), 1); v.g = vode_ptr(c, c->Gc(), 1);
@@ -2179,13 +2187,25 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   const int tp = 0;
   c->lazy_T = 2;       // profile the steady state of a T-step loop: where the path defers the vode update into the next
                        // step's launch (D = 64 fused), every profiled step carries the previous one's
-  infer_step(c, tp);   // warm
-  HCHECK(hipStreamSynchronize(c->st));
+  // warm: the set-up above (allocations, copies, synchronisations) leaves the GPU idle for tens of milliseconds and its
+  // clocks take tens of milliseconds of load to come back (kernel trace, scripts/prof_trace.sh: the same launch runs
+  // 208 us in the first batch after an idle period and 188 us from the third on) -- run steps for >= 60 ms first, so the
+  // launches below are timed at the clocks the timed region of a benchmark runs at
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    int rcw = 0;
+    do {
+      for (int i = 0; i < 32 && !rcw; ++i) rcw = infer_step(c, tp);
+      HCHECK(hipStreamSynchronize(c->st));
+    } while (!rcw && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 0.06);
+    if (rcw) { c->lazy_T = 0; hipFree(hsave); hipFree(msave); return rcw; }
+  }
   c->prof = true; c->recs.clear();
+  c->prof_burst = 8;
   const int reps = 5;
   int rc = 0;
   for (int i = 0; i < reps && !rc; ++i) rc = infer_step(c, tp);
-  c->prof = false;
+  c->prof = false; c->prof_burst = 1;
   if (!rc) rc = flush_lazy_update(c);
   c->lazy_T = 0;
   HCHECK(hipStreamSynchronize(c->st));
@@ -2193,6 +2213,7 @@ int cora_profile_step(cora_ctx* c, int cap, char* names, int* launches, double* 
   for (auto& r : c->recs) {
     float t = 0.f;
     hipEventElapsedTime(&t, r.e0, r.e1);
+    t /= (float)r.n;   // a burst counts as ONE launch of its average duration: per-step sums stay per-step
     launches[r.kind] += 1; ms[r.kind] += t; flops[r.kind] += r.flops; bytes[r.kind] += r.bytes;
     hipEventDestroy(r.e0); hipEventDestroy(r.e1);
   }
