@@ -143,6 +143,10 @@ def parse_args(argv=None):
     ap.add_argument("--dp-backend", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: 'rccl' = collectives inside the captured graphs (cora_step_dist), "
                          "'torch' = step split at the exchange point, torch.distributed all-reduce")
+    ap.add_argument("--dist-graphs", action="store_true",
+                    help="N > 1 with --dp-backend rccl: replay the step as two captured graphs with the collectives as graph "
+                         "nodes (agreed across ranks first).  Default at N > 1: eager launches of the same sequence -- measured "
+                         "equal on one GPU (DESIGN.md section 5) and the mode every RCCL deployment exercises")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="rank processes only rendezvous (gloo) and report: exercises the launcher and the shape of "
                          "the N > 1 line without a GPU")
@@ -349,9 +353,14 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
     # Warm-up.  In-library RCCL: the first call runs eagerly, then the ranks agree (over the torch group, before any
     # replay) on graph replay vs eager collectives.  A step that fails here is an error, not a reason to fall back:
     # the peers may already be inside a collective, and the watchdog / launcher end the run.
+    # Graph replay of the collectives is the default on one GPU (CORA_FORCE_DP, tested there) and opt-in (--dist-graphs)
+    # with more than one rank: it has never run on > 1 GPU and measures equal to eager launches on one.
+    dist_graphs = dp is not None and dp.in_library and (world == 1 or args.dist_graphs)
+    if dp is not None and dp.in_library and not dist_graphs:
+        _lib.check(lib.cora_dist_set_eager(ctx, 1), ctx)
     for k in range(max(warmup, 1)):
         one_step()
-        if k == 0 and dp is not None and dp.in_library:
+        if k == 0 and dist_graphs:
             dp.agree_on_graphs(model, T)
     barrier()
     per_call = np.zeros(steps, dtype=np.float64)
