@@ -1,6 +1,7 @@
-// fused_wide2.hip -- the fused per-(block, image) kernel for the canonical 12-block sweep point
-// (N = 64 tokens, D = 128, heads of 32: /root/reference/sweeps/sweep_12block_comprehensive.yaml:8-47),
-// built for TWO workgroups per CU.
+// fused_wide2.hip -- the fused per-(block, image) kernel for the D = 128 points of the 12-block sweep grid
+// (N = 64 tokens, D = 128, 4 / 2 / 1 heads: /root/reference/sweeps/sweep_12block_comprehensive.yaml:8-47),
+// built for TWO workgroups per CU.  Heads of 32 (the canonical point) are the native form; heads of 64 / 128 run
+// on the same 32-column head tiles with the scores accumulated across a head's slices (wide2_attn_*_sliced).
 //
 // Same math and the same data layout "T" as fused_wide.hip (block /root/reference/pcx/nn/_layer.py:428-447,
 // attention :359-402, LayerNorm :296-315, double residual /root/reference/src/decoder_transformer.py:238,
@@ -107,6 +108,270 @@ __device__ __forceinline__ void store_slice(const float* f, float* base, int grp
     *reinterpret_cast<float4*>(base + 16 * c + 4 * grp) = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
 }
 
+// ---- heads wider than one 32-column slice (D = 128 with 2 or 1 heads) -----------------------------------
+// The head tiles stay 32 columns wide; a head of NS slices accumulates its score-shaped products (S, dP: a
+// contraction over the head dim) across the slices' tiles and runs the products that sum over tokens (O, dq,
+// dK, dV: one 32-column slice of the output each) slice by slice.  A workgroup still walks through 24 head
+// tiles in the backward and 8 in the forward whatever H is, so the LDS budget and the two workgroups per CU
+// of the heads-of-32 form carry over.  Slice s = columns [32 s, 32 s + 32) = registers [8 s, 8 s + 8) of a row.
+constexpr int W2_LDH = 36, W2_HT = 64 * W2_LDH, W2_LDT = 68;
+
+// softmax over the 64 keys of S[key][q] (this lane: query i; keys 16 ot + 4 grp + reg): pf = P, returns the
+// base-2 log-sum-exp of the scaled scores
+__device__ __forceinline__ float softmax_keys(const f32x4* sa, float* pf, float sc) {
+  unpack_at<4>(sa, pf, 0);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { pf[k] *= sc; mx = fmaxf(mx, pf[k]); }
+  mx = grp_max(mx);
+  float ls = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { pf[k] = __builtin_amdgcn_exp2f(pf[k] - mx); ls += pf[k]; }
+  ls = grp_sum(ls);
+  const float inv = 1.0f / ls;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pf[k] *= inv;
+  return mx + __builtin_amdgcn_logf(ls);
+}
+// P and dS of the key-owner pass from S[q][key] (sp) and dP[q][key] (dp): sp <- P, dp <- dS
+__device__ __forceinline__ void p_ds_keys(float* sp, float* dp, const float* lse, const float* delta, float sc, int grp) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const float4 l4 = *reinterpret_cast<const float4*>(&lse[16 * tt + 4 * grp]);
+    const float4 d4 = *reinterpret_cast<const float4*>(&delta[16 * tt + 4 * grp]);
+    float pv;
+    pv = __builtin_amdgcn_exp2f(sp[4 * tt + 0] * sc - l4.x); sp[4 * tt + 0] = pv; dp[4 * tt + 0] = pv * (dp[4 * tt + 0] - d4.x);
+    pv = __builtin_amdgcn_exp2f(sp[4 * tt + 1] * sc - l4.y); sp[4 * tt + 1] = pv; dp[4 * tt + 1] = pv * (dp[4 * tt + 1] - d4.y);
+    pv = __builtin_amdgcn_exp2f(sp[4 * tt + 2] * sc - l4.z); sp[4 * tt + 2] = pv; dp[4 * tt + 2] = pv * (dp[4 * tt + 2] - d4.z);
+    pv = __builtin_amdgcn_exp2f(sp[4 * tt + 3] * sc - l4.w); sp[4 * tt + 3] = pv; dp[4 * tt + 3] = pv * (dp[4 * tt + 3] - d4.w);
+  }
+}
+
+// forward attention, NS = 2 (two heads of 64) or 4 (one head of 128) slices per head; q / kk / v / of: the wave's
+// rows (32 registers each); t[0..3]: the four head-tile slots; lse (LDS, [H][64]) and st_p (stash row, H x 64)
+// may be null (chain kernel: nothing is kept for a backward)
+template <int H>
+__device__ __forceinline__ void wide2_attn_fwd_sliced(const float* q, const float* kk, const float* v, float* of, float* t0, float* t1,
+                                                      float* t2, float* t3, float* lse, float* st_p, float sc, int w, int i, int grp) {
+  constexpr int NS = 4 / H;
+  static_assert(H == 1 || H == 2, "sliced form: D = 128 with heads of 64 or 128");
+  if constexpr (NS == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {      // one head per round: K_a, V_a^T, K_b, V_b^T
+      const int a = 2 * h, b = 2 * h + 1;
+      __syncthreads();                 // the previous round's tiles are no longer read
+      put_slice<W2_LDH, 2>(kk + 8 * a, t0, w, i, grp);
+      put_slice_t<W2_LDT, 2>(v + 8 * a, t1, w, i, grp);
+      put_slice<W2_LDH, 2>(kk + 8 * b, t2, w, i, grp);
+      put_slice_t<W2_LDT, 2>(v + 8 * b, t3, w, i, grp);
+      __syncthreads();
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+      gemm_hd<W2_LDH, 2>(t0, q + 8 * a, sa, i, grp);          // S[key][q], summed over the head's two slices
+      gemm_hd<W2_LDH, 2>(t2, q + 8 * b, sa, i, grp);
+      float pf[16];
+      const float l2 = softmax_keys(sa, pf, sc);
+      if (lse && grp == 0) lse[64 * h + 16 * w + i] = l2;
+      if (st_p) store_row<4>(pf, st_p + 64 * h, grp);
+      accum_t<W2_LDT, 2>(t1, pf, of + 8 * a, 1.0f, i, grp);   // O, one slice of the head's columns at a time
+      accum_t<W2_LDT, 2>(t3, pf, of + 8 * b, 1.0f, i, grp);
+    }
+  } else {
+    float* const tt[4] = {t0, t1, t2, t3};
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) put_slice<W2_LDH, 2>(kk + 8 * s_, tt[s_], w, i, grp);      // round 1: the four K slices
+    __syncthreads();
+    f32x4 sa[4];
+    zero_acc<4>(sa);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) gemm_hd<W2_LDH, 2>(tt[s_], q + 8 * s_, sa, i, grp);
+    float pf[16];
+    const float l2 = softmax_keys(sa, pf, sc);
+    if (lse && grp == 0) lse[16 * w + i] = l2;
+    if (st_p) store_row<4>(pf, st_p, grp);
+    __syncthreads();                   // every wave is past its reads of the K tiles
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) put_slice_t<W2_LDT, 2>(v + 8 * s_, tt[s_], w, i, grp);     // round 2: the four V^T slices
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) accum_t<W2_LDT, 2>(tt[s_], pf, of + 8 * s_, 1.0f, i, grp);
+  }
+}
+
+// attention backward of the sliced form.  tz: six tile slots of W2_HT floats (weight slot 1, idle here, and the
+// head-tile area behind it); dof: dO of the wave's rows; dq lands in dy; dk | dv go to the stash row st_dkv.
+// Per head 6 NS tiles pass through the six slots in NS phases:
+//   NS = 2:  [V_a V_b K_a^T K_b^T Q_a Q_b]  -> dP[key][q], delta, dS, dq ; S[q][key]
+//            [dO_a dO_b dO_a^T dO_b^T Q_a^T Q_b^T] -> dP[q][key], P, dS ; dV, dK
+//   NS = 4:  [V_0..3 K_0^T K_1^T] -> dP, delta, dS, dq_0, dq_1      [K_2^T K_3^T Q_0..3] -> dq_2, dq_3 ; S
+//            [dO_0..3 dO_0^T dO_1^T] -> dP, P, dS ; dV_0, dV_1       [dO_2^T dO_3^T Q_0^T..Q_3^T] -> dV_2, dV_3 ; dK
+template <int H>
+__device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* lse, float* delta, const float* st_q, const float* st_k,
+                                                      const float* st_v, const float* st_p, float* st_dkv, const float* dof, float* dy,
+                                                      float sc, float qscale, int w, int i, int grp) {
+  constexpr int NS = 4 / H, D = 128;
+  static_assert(H == 1 || H == 2, "sliced form: D = 128 with heads of 64 or 128");
+  float* const z[6] = {tz, tz + W2_HT, tz + 2 * W2_HT, tz + 3 * W2_HT, tz + 4 * W2_HT, tz + 5 * W2_HT};
+  if constexpr (NS == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int a = 2 * h, b = 2 * h + 1;
+      float ks[16], vs[16], qs[16], pf[16], dp[16], sp[16];
+      load_slice<4>(ks, st_k + 64 * h, grp);
+      load_slice<4>(vs, st_v + 64 * h, grp);
+      load_slice<4>(qs, st_q + 64 * h, grp);
+      load_row<4>(pf, st_p + 64 * h, grp);
+      __syncthreads();                 // the previous head's tiles (and weight tile 21 NQ - 1) are no longer read
+      put_slice<W2_LDH, 2>(vs, z[0], w, i, grp);
+      put_slice<W2_LDH, 2>(vs + 8, z[1], w, i, grp);
+      put_slice_t<W2_LDT, 2>(ks, z[2], w, i, grp);
+      put_slice_t<W2_LDT, 2>(ks + 8, z[3], w, i, grp);
+      put_slice<W2_LDH, 2>(qs, z[4], w, i, grp);
+      put_slice<W2_LDH, 2>(qs + 8, z[5], w, i, grp);
+      __syncthreads();
+      {
+        // own queries: dP[key][q] = V[key] . dO[q] over both slices, delta = sum_key P dP, dS, dq slice by slice
+        f32x4 sa[4];
+        zero_acc<4>(sa);
+        gemm_hd<W2_LDH, 2>(z[0], dof + 8 * a, sa, i, grp);
+        gemm_hd<W2_LDH, 2>(z[1], dof + 8 * b, sa, i, grp);
+        unpack_at<4>(sa, dp, 0);
+        float dl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+        dl = grp_sum(dl);
+        if (grp == 0) delta[64 * h + 16 * w + i] = dl;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);
+        accum_t<W2_LDT, 2>(z[2], dp, dy + 8 * a, qscale, i, grp);
+        accum_t<W2_LDT, 2>(z[3], dp, dy + 8 * b, qscale, i, grp);
+        // own keys, first half: S[q][key] over both slices
+        zero_acc<4>(sa);
+        gemm_hd<W2_LDH, 2>(z[4], ks, sa, i, grp);
+        gemm_hd<W2_LDH, 2>(z[5], ks + 8, sa, i, grp);
+        unpack_at<4>(sa, sp, 0);
+      }
+      __syncthreads();                 // delta of all 64 queries visible; the first six tiles are no longer read
+      put_slice<W2_LDH, 2>(dof + 8 * a, z[0], w, i, grp);
+      put_slice<W2_LDH, 2>(dof + 8 * b, z[1], w, i, grp);
+      put_slice_t<W2_LDT, 2>(dof + 8 * a, z[2], w, i, grp);
+      put_slice_t<W2_LDT, 2>(dof + 8 * b, z[3], w, i, grp);
+      put_slice_t<W2_LDT, 2>(qs, z[4], w, i, grp);
+      put_slice_t<W2_LDT, 2>(qs + 8, z[5], w, i, grp);
+      __syncthreads();
+      {
+        f32x4 sa[4];
+        zero_acc<4>(sa);
+        gemm_hd<W2_LDH, 2>(z[0], vs, sa, i, grp);               // dP[q][key]
+        gemm_hd<W2_LDH, 2>(z[1], vs + 8, sa, i, grp);
+        unpack_at<4>(sa, dp, 0);
+        p_ds_keys(sp, dp, lse + 64 * h, delta + 64 * h, sc, grp);
+        accum_t<W2_LDT, 2>(z[2], sp, vs, 1.0f, i, grp);          // dV = P^T dO, slice by slice (vs is dead as an operand)
+        accum_t<W2_LDT, 2>(z[3], sp, vs + 8, 1.0f, i, grp);
+        accum_t<W2_LDT, 2>(z[4], dp, ks, qscale, i, grp);        // dK = dS^T Q
+        accum_t<W2_LDT, 2>(z[5], dp, ks + 8, qscale, i, grp);
+        store_slice<4>(ks, st_dkv + 64 * h, grp);
+        store_slice<4>(vs, st_dkv + D + 64 * h, grp);
+      }
+    }
+  } else {
+    float pf[16], dp[16], sp[16];
+    {
+      float vs[32], k2[16];
+      load_row<8>(vs, st_v, grp);
+      load_slice<4>(k2, st_k, grp);
+      load_row<4>(pf, st_p, grp);
+      __syncthreads();                 // weight tile 21 NQ - 1 is no longer read
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) put_slice<W2_LDH, 2>(vs + 8 * s_, z[s_], w, i, grp);
+      put_slice_t<W2_LDT, 2>(k2, z[4], w, i, grp);
+      put_slice_t<W2_LDT, 2>(k2 + 8, z[5], w, i, grp);
+    }
+    __syncthreads();
+    {
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) gemm_hd<W2_LDH, 2>(z[s_], dof + 8 * s_, sa, i, grp);     // dP[key][q]
+      unpack_at<4>(sa, dp, 0);
+      float dl = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+      dl = grp_sum(dl);
+      if (grp == 0) delta[16 * w + i] = dl;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);
+      accum_t<W2_LDT, 2>(z[4], dp, dy, qscale, i, grp);
+      accum_t<W2_LDT, 2>(z[5], dp, dy + 8, qscale, i, grp);
+    }
+    {
+      float k2[16], qs[32];
+      load_slice<4>(k2, st_k + 64, grp);
+      load_row<8>(qs, st_q, grp);
+      __syncthreads();
+      put_slice_t<W2_LDT, 2>(k2, z[0], w, i, grp);
+      put_slice_t<W2_LDT, 2>(k2 + 8, z[1], w, i, grp);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) put_slice<W2_LDH, 2>(qs + 8 * s_, z[2 + s_], w, i, grp);
+    }
+    __syncthreads();
+    {
+      float ks[32];
+      load_row<8>(ks, st_k, grp);
+      accum_t<W2_LDT, 2>(z[0], dp, dy + 16, qscale, i, grp);
+      accum_t<W2_LDT, 2>(z[1], dp, dy + 24, qscale, i, grp);
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) gemm_hd<W2_LDH, 2>(z[2 + s_], ks + 8 * s_, sa, i, grp);  // S[q][key]
+      unpack_at<4>(sa, sp, 0);
+    }
+    __syncthreads();                   // (delta of all queries has been visible since the second barrier)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) put_slice<W2_LDH, 2>(dof + 8 * s_, z[s_], w, i, grp);
+    put_slice_t<W2_LDT, 2>(dof, z[4], w, i, grp);
+    put_slice_t<W2_LDT, 2>(dof + 8, z[5], w, i, grp);
+    {
+      float vs[32];
+      load_row<8>(vs, st_v, grp);
+      __syncthreads();
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) gemm_hd<W2_LDH, 2>(z[s_], vs + 8 * s_, sa, i, grp);      // dP[q][key]
+      unpack_at<4>(sa, dp, 0);
+    }
+    p_ds_keys(sp, dp, lse, delta, sc, grp);
+    {
+      float dv[16];
+      accum_t<W2_LDT, 2>(z[4], sp, dv, 1.0f, i, grp);
+      accum_t<W2_LDT, 2>(z[5], sp, dv + 8, 1.0f, i, grp);
+      store_slice<4>(dv, st_dkv + D, grp);
+    }
+    {
+      float qs[32];
+      load_row<8>(qs, st_q, grp);
+      __syncthreads();
+      put_slice_t<W2_LDT, 2>(dof + 16, z[0], w, i, grp);
+      put_slice_t<W2_LDT, 2>(dof + 24, z[1], w, i, grp);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) put_slice_t<W2_LDT, 2>(qs + 8 * s_, z[2 + s_], w, i, grp);
+    }
+    __syncthreads();
+    {
+      float dv[16];
+      accum_t<W2_LDT, 2>(z[0], sp, dv, 1.0f, i, grp);
+      accum_t<W2_LDT, 2>(z[1], sp, dv + 8, 1.0f, i, grp);
+      store_slice<4>(dv, st_dkv + D + 64, grp);
+      float dk[32];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) accum_t<W2_LDT, 2>(z[2 + s_], dp, dk + 8 * s_, qscale, i, grp);
+      store_row<8>(dk, st_dkv, grp);
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef CORA_STAMPS
@@ -196,12 +461,13 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   constexpr int NQ = D / TR;                      // tiles per D outputs (4)
   constexpr int LD = D + 4, SLOT = TR * LD;
   constexpr int NST = TR * D / 4 / 256;           // staged float4 per thread and tile (4)
-  constexpr int DH = D / H, NCH = DH / 16, RH = 4 * NCH;   // head dim 32: 2 column groups, 8 registers per slice
-  constexpr int LDH = DH + 4, HT = 64 * LDH;      // head tile [64][36]
+  constexpr int DH = D / H, NS = DH / 32;         // head dim 32 (one slice per head), 64 (two) or 128 (four)
+  constexpr int NCH = 2, RH = 8;                  // a slice: 2 column groups, 8 registers
+  constexpr int LDH = 32 + 4, HT = 64 * LDH;      // head tile [64][36]
   constexpr int LDT = 64 + 4;                     // transposed head tile [32][68] (fits the same slot)
-  static_assert(DH * LDT <= HT, "transposed tile fits a head-tile slot");
+  static_assert(32 * LDT <= HT && LDH == W2_LDH && LDT == W2_LDT, "transposed tile fits a head-tile slot");
   constexpr int NT = 24 * NQ;                     // 96 tiles
-  static_assert(DH == 32 && TR * D % 1024 == 0 && NST * 2 <= NCT, "built for heads of 32");
+  static_assert(H * NS * 32 == D && TR * D % 1024 == 0 && NST * 2 <= NCT, "built for 32-column head slices");
   const float qscale = rsqrtf((float)DH);
   const float sc = qscale * CORA_LOG2E;
 
@@ -210,7 +476,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   float* tB = tA + HT;
   float* tC = tB + HT;
   float* tD = tC + HT;
-  float* rowc = tD + HT;                 // lse2[H][64], delta[H][64]
+  // lse2[H][64], delta[H][64]; the sliced form's backward uses six full slots from weight slot 1 on (384 floats more)
+  float* rowc = NS == 1 ? tD + HT : lds + SLOT + 6 * HT;
   float* pb = rowc + 2 * H * 64;         // [b1 M | ln2 gamma D | ln2 beta D | b2 D | ln1 gamma D]
   constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D, PB_LN1G = M + 3 * D;
 
@@ -324,6 +591,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     W2STAMP(2);
     // attention, two heads per round: K_h, V_h slices of all 64 tokens in the head tiles
     float of[R];
+    if constexpr (NS > 1) {
+      wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, rowc, st_p, sc, w, i, grp);
+    } else {
 #pragma unroll
     for (int hp = 0; hp < H; hp += 2) {
       __syncthreads();                   // the previous round's tiles are no longer read
@@ -357,6 +627,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         store_row<4>(pf, st_p + 64 * h, grp);
         accum_t<LDT, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);    // O, this head's columns (V_h transposed)
       }
+    }
     }
     W2STAMP(3);
     if (LAZY) {   // the target vode's rows with the deferred update applied, parked in this workgroup's slot of the error
@@ -460,14 +731,18 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     // LDS read per four MFMAs).  They fill the four forward tile slots plus the weight slot that is free
     // here (tile 21 NQ already sits in slot 0, tile 21 NQ + 1 in registers).  dq lands in dy, dk / dv go
     // to the stash until the last GEMM reads them.
-    static_assert((21 * NQ) % 2 == 0 && 3 * HT + 3 * DH * LDT <= SLOT + 4 * HT, "six backward head tiles fit slot 1 + the head tiles");
+    static_assert((21 * NQ) % 2 == 0 && 3 * HT + 3 * 32 * LDT <= SLOT + 4 * HT, "six backward head tiles fit slot 1 + the head tiles");
     float* bV = wbuf + SLOT;
     float* bKT = bV + HT;
-    float* bQ = bKT + DH * LDT;
+    float* bQ = bKT + 32 * LDT;
     float* bdO = bQ + HT;
     float* bQT = bdO + HT;
-    float* bdOT = bQT + DH * LDT;
+    float* bdOT = bQT + 32 * LDT;
     float* delta = rowc + 64 * H;
+    if constexpr (NS > 1) {
+      // heads of 64 / 128: the same tiles, 32-column slice by slice, scores accumulated across a head's slices
+      wide2_attn_bwd_sliced<H>(wbuf + SLOT, rowc, delta, st_q, st_k, st_v, st_p, st_dkv, dof, dy, sc, qscale, w, i, grp);
+    } else {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float ks[RH], vs[RH], pf[16], dp[16];
@@ -524,6 +799,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
         store_slice<NCH>(vs, st_dkv + D + 16 * NCH * h, grp);
       }
     }
+    }
   }
   W2STAMP(11);
   {
@@ -563,11 +839,11 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
   constexpr int NOT = 2, TR = 32;
   constexpr int NQ = D / TR;
   constexpr int LD = D + 4, SLOT = TR * LD;
-  constexpr int DH = D / H, NCH = DH / 16, RH = 4 * NCH;
-  constexpr int LDH = DH + 4, HT = 64 * LDH;
+  constexpr int DH = D / H, NS = DH / 32, NCH = 2, RH = 8;
+  constexpr int LDH = 32 + 4, HT = 64 * LDH;
   constexpr int LDT = 64 + 4;
   constexpr int TPB = 12 * NQ;                    // forward tiles per block (48)
-  static_assert(DH == 32 && NCT == 8, "built for D = 128, heads of 32");
+  static_assert(H * NS * 32 == D && NCT == 8, "built for D = 128, 32-column head slices");
   const int NT = TPB * p.L;
   const float sc = rsqrtf((float)DH) * CORA_LOG2E;
 
@@ -631,6 +907,9 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
         GEMM_D(k0 + 2 * NQ, xn, v)
       }
       float of[R];
+      if constexpr (NS > 1) {
+        wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, nullptr, nullptr, sc, w, i, grp);
+      } else {
 #pragma unroll
       for (int hp = 0; hp < H; hp += 2) {
         __syncthreads();                 // the previous round's tiles are no longer read
@@ -662,6 +941,7 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
           for (int k = 0; k < 16; ++k) pf[k] *= inv;
           accum_t<LDT, NCH>(tV, pf, of + RH * h, 1.0f, i, grp);    // O, this head's columns
         }
+      }
       }
       GEMM_D(k0 + 3 * NQ, of, y)           // y = x + att Wo^T
       {
@@ -729,13 +1009,22 @@ __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
 }
 
 size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
-// P == 48: the edge layers (edge_path_wide, fused_wide_common.h) are written for the 4x4x3 patch of the sweep configs
-bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && H == 4 && M == 4 * D && P == 48; }
+// P == 48: the edge layers (edge_path_wide, fused_wide_common.h) are written for the 4x4x3 patch of the sweep configs.
+// H = 4: heads of 32, one slice per head; H = 2 / 1: heads of 64 / 128 as two / four 32-column slices (sliced form)
+bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && (H == 4 || H == 2 || H == 1) && M == 4 * D && P == 48; }
 
-int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
+namespace {
+// dynamic LDS: 2 weight slots | 4 head tiles (sliced form: + 384 floats, see wide2_block_body) | lse, delta | parameter block
+constexpr size_t wide2_lds_bytes(int H) {
+  return (size_t)(2 * 32 * (128 + 4) + 4 * 64 * 36 + (H == 4 ? 0 : 384) + 2 * H * 64 + 512 + 4 * 128) * sizeof(float);
+}
+static_assert(2 * wide2_lds_bytes(2) <= 160 * 1024 && 2 * wide2_lds_bytes(1) <= 160 * 1024 && 2 * wide2_lds_bytes(4) <= 160 * 1024,
+              "two workgroups per CU");
+template <int H>
+int launch_fused_wide2_h(const FusedP& p, int L, hipStream_t st) {
   static bool attr[64] = {};
-  constexpr int NCT = 8, H = 4, D = 128, M = 512;
-  const size_t sm = (size_t)(2 * 32 * (D + 4) + 4 * 64 * 36 + 2 * H * 64 + M + 4 * D) * sizeof(float);
+  constexpr int NCT = 8;
+  constexpr size_t sm = wide2_lds_bytes(H);
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
@@ -744,18 +1033,37 @@ int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
   else hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H, false>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
-
-// the L blocks of the status-"forward" chain for every image (see wide2_chain_body)
-int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st) {
+template <int H>
+int launch_chain_wide2_h(const FusedP& p, const float* xin, float* xout, long long stride, hipStream_t st) {
   static bool attr[64] = {};
-  constexpr int NCT = 8, H = 4, D = 128, M = 512;
-  const size_t sm = (size_t)(2 * 32 * (D + 4) + 4 * 64 * 36 + 2 * H * 64 + M + 4 * D) * sizeof(float);
-  if (L < 1 || p.L != L) return -1;
+  constexpr int NCT = 8;
+  constexpr size_t sm = wide2_lds_bytes(H);
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_chain_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
   }
   hipLaunchKernelGGL((pc_chain_wide2_kernel<NCT, H>), dim3(p.B), dim3(256), sm, st, p, xin, xout, stride);
   return 0;
+}
+}  // namespace
+
+int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
+  switch (p.H) {
+    case 4: return launch_fused_wide2_h<4>(p, L, st);
+    case 2: return launch_fused_wide2_h<2>(p, L, st);
+    case 1: return launch_fused_wide2_h<1>(p, L, st);
+  }
+  return -1;
+}
+
+// the L blocks of the status-"forward" chain for every image (see wide2_chain_body)
+int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st) {
+  if (L < 1 || p.L != L) return -1;
+  switch (p.H) {
+    case 4: return launch_chain_wide2_h<4>(p, xin, xout, stride, st);
+    case 2: return launch_chain_wide2_h<2>(p, xin, xout, stride, st);
+    case 1: return launch_chain_wide2_h<1>(p, xin, xout, stride, st);
+  }
+  return -1;
 }
 #undef STAGE
 #undef GEMM_CT

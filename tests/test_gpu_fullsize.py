@@ -68,7 +68,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("config,over,T", [
     ("6block", {}, 20),                                     # cfg 2: the D = 64 fused kernel
     ("12block", {}, 20),                                    # cfg 3 canonical: D = 128, H = 4 on the wide fused kernel
-    ("12block", {"hidden_size": 128, "num_heads": 1}, 6),   # head dim 128: P / dS handed over through LDS
+    ("12block", {"hidden_size": 128, "num_heads": 1}, 6),   # head dim 128 as four 32-column slices (wide2, sliced form)
+    ("12block", {"hidden_size": 128, "num_heads": 2}, 6),   # head dim 64 as two slices
     ("12block", {"hidden_size": 96, "num_heads": 4}, 6),    # head dim 24: heads share a column group
     ("12block", {"hidden_size": 96, "num_heads": 2}, 6),
 ])

@@ -40,7 +40,10 @@ CASES = {
     "cfg3_shape_B2": ((3, 32, 32), 4, 128, 4, 12, 2, 3),
     # pc_block_wide2_kernel at a depth where no fp32 floor relaxes a bar: its VJP held to the plain 1e-4 on every gh
     "d128_h4_shallow": ((3, 32, 32), 4, 128, 4, 2, 2, 3),
-    "d128_h1_shallow": ((3, 32, 32), 4, 128, 1, 2, 2, 3),      # pc_block_wide_kernel (one workgroup per CU form), head dim 128
+    # heads of 128 / 64 on the same kernel: 32-column slices, scores accumulated across a head's slices (sliced form)
+    "d128_h1_shallow": ((3, 32, 32), 4, 128, 1, 2, 2, 3),
+    "d128_h2_shallow": ((3, 32, 32), 4, 128, 2, 2, 3, 3),
+    "d128_h2_12block": ((3, 32, 32), 4, 128, 2, 12, 2, 3),
     # N = 64 and D = 96 / 128 but a patch dim other than 48: the wide fused kernels' edge layers are written for
     # P = 48, so these must take the per-op path (asserted in test_wide_kernels_need_patch_dim_48)
     "d128_h4_P16": ((1, 32, 32), 4, 128, 4, 2, 2, 3),
@@ -136,6 +139,14 @@ def test_wide_kernels_need_patch_dim_48(name, path):
     4x4x3 patch (fused_wide_common.h: edge_path_wide) -- so a 64-token config with another patch dim (a 1-channel
     32x32 image: P = 16; 64x64 with 8x8 patches: P = 192) runs the per-op path, and passes the same bars there."""
     run_case(name, expect_path=path)
+
+
+@pytest.mark.parametrize("name", ["d128_h1_shallow", "d128_h2_shallow", "d128_h4_shallow"])
+def test_one_workgroup_wide_kernel_at_d128(name, monkeypatch):
+    """CORA_WIDE1=1: D = 128 on pc_block_wide_kernel (one workgroup per CU, K / V of all heads in LDS) instead of
+    pc_block_wide2_kernel -- the form the D = 96 points still run, kept reachable at D = 128 as the second implementation."""
+    monkeypatch.setenv("CORA_WIDE1", "1")
+    run_case(name, expect_path="fused-wide")
 
 
 def test_regularisers_and_clipping():
@@ -234,7 +245,7 @@ def test_fused_pair_kernel_matches_four_wave_kernel_at_B25(H, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
-@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg"])
+@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg", "wide2_h2", "wide2_h1_reg"])
 def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     """D = 64 fused path and the D = 128 / heads-of-32 kernel (wide2): inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
     of step t + 1 as it loads its rows (FusedP::lazy, vodes / momentum / gradients ping-ponging between two arena
@@ -243,7 +254,8 @@ def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     clip firing, with per-leaf gradient normalisation, with regularisers, for odd and even numbers of deferred
     updates (T - 1), and across two batches (the second replays the captured graph)."""
     import cora_amd as ca
-    D, H = {"h1": (64, 1), "h2_gradnorm": (64, 2), "h4_reg": (64, 4), "wide2": (128, 4), "wide2_gradnorm_reg": (128, 4)}[variant]
+    D, H = {"h1": (64, 1), "h2_gradnorm": (64, 2), "h4_reg": (64, 4), "wide2": (128, 4), "wide2_gradnorm_reg": (128, 4),
+            "wide2_h2": (128, 2), "wide2_h1_reg": (128, 1)}[variant]
     kw = dict(clip_h=3.0, clip_w=0.5)
     if "gradnorm" in variant:
         kw.update(use_grad_norm=True, grad_norm_target=2.0)
