@@ -261,12 +261,12 @@ int launch_chain(const FusedP& p, int store_h, hipStream_t st);
 // wide variant (fused_wide.hip): N = 64, D = 96 / 128, inference step only; uses H1, E2, BP1, W, WT, S_stash, S_da
 bool fused_wide_supported(int N, int P, int D, int H, int M);
 int launch_fused_wide(const FusedP& p, int L, int D, hipStream_t st);
-// two workgroups per CU (fused_wide2.hip): D = 128, heads of 32; also uses S_dqkv as a dk | dv stash
+// two workgroups per CU (fused_wide2.hip): D = 128 (4 / 2 / 1 heads), D = 96 (2 / 1 heads); also uses S_dqkv as a dk | dv stash
 bool fused_wide2_supported(int N, int P, int D, int H, int M);
-int launch_fused_wide2(const FusedP& p, int L, hipStream_t st);
+int launch_fused_wide2(const FusedP& p, int L, int D, hipStream_t st);
 // status-"forward" walk of one image per workgroup through all L blocks (D = 128, heads of 32); in place when
 // stride == 0 and xin == xout, else block g's output goes to xout + g * stride
-int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st);
+int launch_chain_wide2(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st);
 // the same for every shape fused_wide_supported() takes (one workgroup per CU form)
 int launch_chain_wide(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st);
 // ---- row-tile fused kernels (fused_rows.hip): D = 64, M = 256, any sequence length ---------------------------

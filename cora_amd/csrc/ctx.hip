@@ -664,7 +664,7 @@ int infer_grad_step(cora_ctx* c, int t) {
       const int nb = c->prof ? c->prof_burst : 1;   // burst under one event pair, as on the D = 64 path
       KScope s(c, K_FUSED, block_step_flops(c) + 8.0 * c->B * (double)c->N * c->P * c->D, 4.0 * 4 * L * c->nl + (lazy ? 20.0 * c->nV : 0.0), nb);
       for (int i = 0; i < nb; ++i)
-        if (c->fusedw2 ? launch_fused_wide2(f, L, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
+        if (c->fusedw2 ? launch_fused_wide2(f, L, c->D, c->st) : launch_fused_wide(f, L, c->D, c->st)) FAIL(-3, "wide fused block kernel: launch setup failed");
     }
     VodeGradP v; memset(&v, 0, sizeof v);
     v.bp = vode_ptr(c, c->Gc(), 1); v.e = err_ptr(c, 1); v.h = vode_ptr(c, c->Hc(), 1); v.g = vode_ptr(c, c->Gc(), 1);
@@ -821,7 +821,7 @@ int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
       KScope s(c, K_OTHER, fl, 0);
       float* xo = into_vodes ? vode_ptr(c, c->Hs, 2) : cur;
       const long long stride = into_vodes ? c->nl : 0;
-      if (c->fusedw2 ? launch_chain_wide2(f, L, cur, xo, stride, c->st) : launch_chain_wide(f, L, c->D, cur, xo, stride, c->st))
+      if (c->fusedw2 ? launch_chain_wide2(f, L, c->D, cur, xo, stride, c->st) : launch_chain_wide(f, L, c->D, cur, xo, stride, c->st))
         FAIL(-3, "wide chain kernel launch failed");
     }
     out_proj(c, into_vodes ? vode_ptr(c, c->Hs, L + 1) : cur, c->z, OUT_STORE, nullptr, nullptr);

@@ -372,6 +372,125 @@ __device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* ls
   }
 }
 
+// ---- D = 96: heads of 96 as three 32-column slices (NCS = 2), heads of 48 as three 16-column slices (NCS = 1) ----
+// Same scheme with NS = 3; a tile slot is 64 x (16 NCS + 4) floats (its transposed image [16 NCS][68] is smaller),
+// slots at stride TS from `t` (forward: 3 of them in the head-tile area) / `tz` (backward: 6, from weight slot 1 on).
+// Row registers of slice s of head h: [RS (3 h + s), + RS), RS = 4 NCS.
+template <int H, int NCS>
+__device__ __forceinline__ void wide2_attn_fwd_3(const float* q, const float* kk, const float* v, float* of, float* t, float* lse,
+                                                 float* st_p, float sc, int w, int i, int grp) {
+  constexpr int RS = 4 * NCS, LDH = 16 * NCS + 4, TS = 64 * LDH;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    __syncthreads();                   // the previous head's tiles are no longer read
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) put_slice<LDH, NCS>(kk + RS * (3 * h + s_), t + s_ * TS, w, i, grp);
+    __syncthreads();
+    f32x4 sa[4];
+    zero_acc<4>(sa);
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) gemm_hd<LDH, NCS>(t + s_ * TS, q + RS * (3 * h + s_), sa, i, grp);     // S[key][q] over the slices
+    float pf[16];
+    const float l2 = softmax_keys(sa, pf, sc);
+    if (lse && grp == 0) lse[64 * h + 16 * w + i] = l2;
+    if (st_p) store_row<4>(pf, st_p + 64 * h, grp);
+    __syncthreads();                   // every wave is past its reads of the K tiles
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) put_slice_t<W2_LDT, NCS>(v + RS * (3 * h + s_), t + s_ * TS, w, i, grp);
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) accum_t<W2_LDT, NCS>(t + s_ * TS, pf, of + RS * (3 * h + s_), 1.0f, i, grp);
+  }
+}
+// per head three phases of six tiles:  [V_0..2 K_0..2^T] -> dP[key][q], delta, dS, dq     [Q_0..2 dO_0..2] -> S, dP [q][key], P, dS
+//                                      [dO_0..2^T Q_0..2^T] -> dV, dK
+template <int H, int NCS>
+__device__ __forceinline__ void wide2_attn_bwd_3(float* tz, const float* lse, float* delta, const float* st_q, const float* st_k,
+                                                 const float* st_v, const float* st_p, float* st_dkv, const float* dof, float* dy,
+                                                 float sc, float qscale, int w, int i, int grp) {
+  constexpr int RS = 4 * NCS, LDH = 16 * NCS + 4, TS = 64 * LDH, DH = 48 * NCS, D = 96;
+  static_assert(H * DH == D, "D = 96");
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float ks[3 * RS], vs[3 * RS], qs[3 * RS], pf[16], dp[16], sp[16];
+    load_slice<3 * NCS>(ks, st_k + DH * h, grp);
+    load_slice<3 * NCS>(vs, st_v + DH * h, grp);
+    load_slice<3 * NCS>(qs, st_q + DH * h, grp);
+    load_row<4>(pf, st_p + 64 * h, grp);
+    __syncthreads();                   // the previous head's tiles (and weight tile 21 NQ - 1) are no longer read
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      put_slice<LDH, NCS>(vs + RS * s_, tz + s_ * TS, w, i, grp);
+      put_slice_t<W2_LDT, NCS>(ks + RS * s_, tz + (3 + s_) * TS, w, i, grp);
+    }
+    __syncthreads();
+    {
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) gemm_hd<LDH, NCS>(tz + s_ * TS, dof + RS * (3 * h + s_), sa, i, grp);   // dP[key][q]
+      unpack_at<4>(sa, dp, 0);
+      float dl = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+      dl = grp_sum(dl);
+      if (grp == 0) delta[64 * h + 16 * w + i] = dl;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) accum_t<W2_LDT, NCS>(tz + (3 + s_) * TS, dp, dy + RS * (3 * h + s_), qscale, i, grp);   // dq
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      put_slice<LDH, NCS>(qs + RS * s_, tz + s_ * TS, w, i, grp);
+      put_slice<LDH, NCS>(dof + RS * (3 * h + s_), tz + (3 + s_) * TS, w, i, grp);
+    }
+    __syncthreads();                   // (also: delta of all 64 queries visible)
+    {
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) gemm_hd<LDH, NCS>(tz + s_ * TS, ks + RS * s_, sa, i, grp);              // S[q][key]
+      unpack_at<4>(sa, sp, 0);
+      zero_acc<4>(sa);
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) gemm_hd<LDH, NCS>(tz + (3 + s_) * TS, vs + RS * s_, sa, i, grp);        // dP[q][key]
+      unpack_at<4>(sa, dp, 0);
+      p_ds_keys(sp, dp, lse + 64 * h, delta + 64 * h, sc, grp);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      put_slice_t<W2_LDT, NCS>(dof + RS * (3 * h + s_), tz + s_ * TS, w, i, grp);
+      put_slice_t<W2_LDT, NCS>(qs + RS * s_, tz + (3 + s_) * TS, w, i, grp);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) accum_t<W2_LDT, NCS>(tz + s_ * TS, sp, vs + RS * s_, 1.0f, i, grp);               // dV
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) accum_t<W2_LDT, NCS>(tz + (3 + s_) * TS, dp, ks + RS * s_, qscale, i, grp);      // dK
+    store_slice<3 * NCS>(ks, st_dkv + DH * h, grp);
+    store_slice<3 * NCS>(vs, st_dkv + D + DH * h, grp);
+  }
+}
+
+// LDS carve-up shared by the bodies and the launchers (floats): 2 weight slots | head-tile area | lse, delta | parameters
+template <int NCT, int H>
+struct W2Cfg {
+  static constexpr int D = 16 * NCT, M = 4 * D, DH = D / H;
+  static constexpr int SW = (NCT == 6 && H == 2) ? 16 : 32;      // slice width: 32 columns, 16 for heads of 48
+  static constexpr int NS = DH / SW, NCS = SW / 16;
+  static constexpr int NOT = NCT == 6 ? 3 : 2;                  // 16-row output groups of a weight tile (32 rows; D = 96: 48)
+  static constexpr int SLOT = 16 * NOT * (D + 4), HT = 64 * 36, TS = 64 * (SW + 4);
+  static constexpr int FWD_END = 2 * SLOT + 4 * HT;              // forward: four head-tile slots behind the weight slots
+  static constexpr int BWD_END = NS > 1 ? SLOT + 6 * TS : 0;     // sliced backward: six slots from weight slot 1 on
+  static constexpr int TILE_END = FWD_END > BWD_END ? FWD_END : BWD_END;
+  static constexpr int LDS_FLOATS = TILE_END + 2 * H * 64 + M + 4 * D;
+  static_assert(NS * SW == DH && (NCT == 8 ? (H == 4 || H == 2 || H == 1) : (NCT == 6 && (H == 2 || H == 1))), "shape not built");
+  static_assert(2 * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU");
+};
+
 }  // namespace
 
 #ifdef CORA_STAMPS
@@ -393,19 +512,23 @@ __device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* ls
 // The macros name locals both bodies define: tile_src (tile index -> source pointer and row stride), the
 // staging registers sr0..sr3, trow / tcol, wbuf, slot, NT (tiles this workgroup walks through) and the
 // tile geometry constants.
-#define PF_ONE(J, REG, SRC, LDW) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
-#define PB_ONE(J, REG, WB) lds_st4((WB) + 8 * (J) * LD, REG);
+// (D = 96: a tile row is 24 float4, so 192 threads -- waves 0..2 -- stage 8 rows per piece and wave 3 stages nothing)
+#define PF_ONE(J, REG, SRC, LDW) if (stg_) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
+#define PB_ONE(J, REG, WB) if (stg_) lds_st4((WB) + 8 * (J) * LD, REG);
 #define PREFETCH_ALL(K)                                                                           \
   do {                                                                                            \
     int ld_; const float* s_ = tile_src((K), ld_);                                                \
     PF_ONE(0, sr0, s_, ld_) PF_ONE(1, sr1, s_, ld_) PF_ONE(2, sr2, s_, ld_) PF_ONE(3, sr3, s_, ld_) \
+    if constexpr (NPIECE > 4) { PF_ONE(4, sr4, s_, ld_) PF_ONE(5, sr5, s_, ld_) }                 \
   } while (0)
 #define WRITE_ALL(S)                                                                              \
   do {                                                                                            \
     lds_float* wb_ = opaque_w(wbuf + (S) * SLOT + trow * LD + tcol);                              \
     PB_ONE(0, sr0, wb_) PB_ONE(1, sr1, wb_) PB_ONE(2, sr2, wb_) PB_ONE(3, sr3, wb_)               \
+    if constexpr (NPIECE > 4) { PB_ONE(4, sr4, wb_) PB_ONE(5, sr5, wb_) }                         \
   } while (0)
-  // column group C of the multiplication with tile k; the even groups carry one staged float4 each
+  // column group C of the multiplication with tile k; every PSTEP-th group (8 groups: the even ones, 6 groups: the
+  // first four) carries one staged float4
 #define GEMM_CT(C, XF, ACC)                                                                       \
   {                                                                                               \
     if ((C) + 1 < NCT) {                                                                          \
@@ -413,10 +536,14 @@ __device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* ls
         a_[((C) + 1) & 1][ot] = lds_ld4(&tl_[16 * ot * LD + 16 * ((C) + 1)]);                     \
     }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);   /* the reads of group C+1 stay AHEAD of group C's MFMAs */ \
-    if ((C) == 0) { if (do_w_) { PB_ONE(0, sr0, wb_) } if (do_p_) { PF_ONE(0, sr0, ns_, nld_) } } \
-    if ((C) == 2) { if (do_w_) { PB_ONE(1, sr1, wb_) } if (do_p_) { PF_ONE(1, sr1, ns_, nld_) } } \
-    if ((C) == 4) { if (do_w_) { PB_ONE(2, sr2, wb_) } if (do_p_) { PF_ONE(2, sr2, ns_, nld_) } } \
-    if ((C) == 6) { if (do_w_) { PB_ONE(3, sr3, wb_) } if (do_p_) { PF_ONE(3, sr3, ns_, nld_) } } \
+    if ((C) == 0 * PSTEP) { if (do_w_) { PB_ONE(0, sr0, wb_) } if (do_p_) { PF_ONE(0, sr0, ns_, nld_) } } \
+    if ((C) == 1 * PSTEP) { if (do_w_) { PB_ONE(1, sr1, wb_) } if (do_p_) { PF_ONE(1, sr1, ns_, nld_) } } \
+    if ((C) == 2 * PSTEP) { if (do_w_) { PB_ONE(2, sr2, wb_) } if (do_p_) { PF_ONE(2, sr2, ns_, nld_) } } \
+    if ((C) == 3 * PSTEP) { if (do_w_) { PB_ONE(3, sr3, wb_) } if (do_p_) { PF_ONE(3, sr3, ns_, nld_) } } \
+    if constexpr (NPIECE > 4) {                                                                   \
+      if ((C) == 4 * PSTEP) { if (do_w_) { PB_ONE(4, sr4, wb_) } if (do_p_) { PF_ONE(4, sr4, ns_, nld_) } } \
+      if ((C) == 5 * PSTEP) { if (do_w_) { PB_ONE(5, sr5, wb_) } if (do_p_) { PF_ONE(5, sr5, ns_, nld_) } } \
+    }                                                                                             \
     _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].x, (XF)[4 * (C) + 0], (ACC)[ot]); \
     _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].y, (XF)[4 * (C) + 1], (ACC)[ot]); \
     _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) (ACC)[ot] = mfma16(a_[(C) & 1][ot].z, (XF)[4 * (C) + 2], (ACC)[ot]); \
@@ -435,7 +562,8 @@ __device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* ls
     float4 a_[2][NOT];                                                                            \
     _Pragma("unroll") for (int ot = 0; ot < NOT; ++ot) a_[0][ot] = lds_ld4(&tl_[16 * ot * LD]);   \
     GEMM_CT(0, XF, ACC) GEMM_CT(1, XF, ACC) GEMM_CT(2, XF, ACC) GEMM_CT(3, XF, ACC)               \
-    GEMM_CT(4, XF, ACC) GEMM_CT(5, XF, ACC) GEMM_CT(6, XF, ACC) GEMM_CT(7, XF, ACC)               \
+    GEMM_CT(4, XF, ACC) GEMM_CT(5, XF, ACC)                                                       \
+    if constexpr (NCT > 6) { GEMM_CT(6, XF, ACC) GEMM_CT(7, XF, ACC) }                            \
     slot ^= 1;                                                                                    \
     (void)wb_; (void)ns_; (void)nld_;                                                             \
   } while (0)
@@ -457,17 +585,22 @@ __device__ __forceinline__ void wide2_attn_bwd_sliced(float* tz, const float* ls
 template <int NCT, int H, bool LAZY>
 __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, int g, int b) {
   constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
-  constexpr int NOT = 2, TR = 32;                 // weight tile: 32 output rows x D inputs
+  constexpr int NOT = W2Cfg<NCT, H>::NOT, TR = 16 * NOT;   // weight tile: 32 output rows x D inputs (D = 96: 48 rows)
+  constexpr int NPIECE = TR / 8;                  // staged float4 per thread and tile (8 tile rows per piece)
   constexpr int NQ = D / TR;                      // tiles per D outputs (4)
   constexpr int LD = D + 4, SLOT = TR * LD;
-  constexpr int NST = TR * D / 4 / 256;           // staged float4 per thread and tile (4)
-  constexpr int DH = D / H, NS = DH / 32;         // head dim 32 (one slice per head), 64 (two) or 128 (four)
-  constexpr int NCH = 2, RH = 8;                  // a slice: 2 column groups, 8 registers
+  // (four staged float4 per thread and tile: 8 tile rows per piece)
+  using Cfg = W2Cfg<NCT, H>;
+  constexpr int DH = D / H, NS = Cfg::NS;         // slices per head: 32 columns each (16 for heads of 48)
+  constexpr int NCH = 2, RH = 8;                  // heads-of-32 form: a head = one slice of 2 column groups, 8 registers
   constexpr int LDH = 32 + 4, HT = 64 * LDH;      // head tile [64][36]
   constexpr int LDT = 64 + 4;                     // transposed head tile [32][68] (fits the same slot)
-  static_assert(32 * LDT <= HT && LDH == W2_LDH && LDT == W2_LDT, "transposed tile fits a head-tile slot");
-  constexpr int NT = 24 * NQ;                     // 96 tiles
-  static_assert(H * NS * 32 == D && TR * D % 1024 == 0 && NST * 2 <= NCT, "built for 32-column head slices");
+  static_assert(32 * LDT <= HT && LDH == W2_LDH && LDT == W2_LDT && SLOT == Cfg::SLOT && HT == Cfg::HT, "transposed tile fits a head-tile slot");
+  constexpr int NT = 24 * NQ;                     // 96 tiles (D = 96: 72)
+  constexpr int PSTEP = NCT / NPIECE;             // staged pieces ride on column groups 0, PSTEP, 2 PSTEP, ...
+  constexpr int SLOT0 = (21 * NQ) & 1;            // first tile's slot: chosen so that tile 21 NQ sits in slot 0 and slot 1 --
+                                                  // next to the head tiles -- idles during the attention backward
+  static_assert(NCT == 8 || NCT == 6, "weight-tile pipeline: 8 or 6 column groups");
   const float qscale = rsqrtf((float)DH);
   const float sc = qscale * CORA_LOG2E;
 
@@ -476,8 +609,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
   float* tB = tA + HT;
   float* tC = tB + HT;
   float* tD = tC + HT;
-  // lse2[H][64], delta[H][64]; the sliced form's backward uses six full slots from weight slot 1 on (384 floats more)
-  float* rowc = NS == 1 ? tD + HT : lds + SLOT + 6 * HT;
+  float* rowc = lds + Cfg::TILE_END;     // lse2[H][64], delta[H][64]
   float* pb = rowc + 2 * H * 64;         // [b1 M | ln2 gamma D | ln2 beta D | b2 D | ln1 gamma D]
   constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D, PB_LN1G = M + 3 * D;
 
@@ -545,12 +677,13 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     ldw = 3 * D; return WqkvT + (long long)(j % NQ) * TR * 3 * D + (long long)(j / NQ) * D;
   };
   const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
-  float4 sr0, sr1, sr2, sr3;
-  int slot = 0;
-  static_assert(NCT == 8, "GEMM_CT is written out for 8 column groups");
+  const bool stg_ = (8 * (D / 4) >= 256) || tid < 8 * (D / 4);
+  float4 sr0, sr1, sr2, sr3, sr4, sr5;
+  (void)sr4; (void)sr5;
+  int slot = SLOT0;
 
   PREFETCH_ALL(0);
-  WRITE_ALL(0);                    // tile 0 -> slot 0 (visible after stage 0's barrier)
+  WRITE_ALL(SLOT0);                // tile 0 -> its slot (visible after stage 0's barrier)
   PREFETCH_ALL(1);
   W2STAMP(0);
 
@@ -591,7 +724,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     W2STAMP(2);
     // attention, two heads per round: K_h, V_h slices of all 64 tokens in the head tiles
     float of[R];
-    if constexpr (NS > 1) {
+    if constexpr (NS == 3) {
+      wide2_attn_fwd_3<H, Cfg::NCS>(q, kk, v, of, tA, rowc, st_p, sc, w, i, grp);
+    } else if constexpr (NS > 1) {
       wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, rowc, st_p, sc, w, i, grp);
     } else {
 #pragma unroll
@@ -731,7 +866,7 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     // LDS read per four MFMAs).  They fill the four forward tile slots plus the weight slot that is free
     // here (tile 21 NQ already sits in slot 0, tile 21 NQ + 1 in registers).  dq lands in dy, dk / dv go
     // to the stash until the last GEMM reads them.
-    static_assert((21 * NQ) % 2 == 0 && 3 * HT + 3 * 32 * LDT <= SLOT + 4 * HT, "six backward head tiles fit slot 1 + the head tiles");
+    static_assert((21 * NQ + SLOT0) % 2 == 0 && (NS > 1 || 3 * HT + 3 * 32 * LDT <= SLOT + 4 * HT), "six backward head tiles fit slot 1 + the head tiles");
     float* bV = wbuf + SLOT;
     float* bKT = bV + HT;
     float* bQ = bKT + 32 * LDT;
@@ -739,7 +874,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     float* bQT = bdO + HT;
     float* bdOT = bQT + 32 * LDT;
     float* delta = rowc + 64 * H;
-    if constexpr (NS > 1) {
+    if constexpr (NS == 3) {
+      wide2_attn_bwd_3<H, Cfg::NCS>(wbuf + SLOT, rowc, delta, st_q, st_k, st_v, st_p, st_dkv, dof, dy, sc, qscale, w, i, grp);
+    } else if constexpr (NS > 1) {
       // heads of 64 / 128: the same tiles, 32-column slice by slice, scores accumulated across a head's slices
       wide2_attn_bwd_sliced<H>(wbuf + SLOT, rowc, delta, st_q, st_k, st_v, st_p, st_dkv, dof, dy, sc, qscale, w, i, grp);
     } else {
@@ -836,14 +973,15 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
 template <int NCT, int H>
 __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, int b, const float* xin, float* xout, long long stride) {
   constexpr int D = 16 * NCT, M = 4 * D, R = 4 * NCT;
-  constexpr int NOT = 2, TR = 32;
+  constexpr int NOT = W2Cfg<NCT, H>::NOT, TR = 16 * NOT, NPIECE = TR / 8;
   constexpr int NQ = D / TR;
   constexpr int LD = D + 4, SLOT = TR * LD;
-  constexpr int DH = D / H, NS = DH / 32, NCH = 2, RH = 8;
+  using Cfg = W2Cfg<NCT, H>;
+  constexpr int DH = D / H, NS = Cfg::NS, NCH = 2, RH = 8;
   constexpr int LDH = 32 + 4, HT = 64 * LDH;
   constexpr int LDT = 64 + 4;
-  constexpr int TPB = 12 * NQ;                    // forward tiles per block (48)
-  static_assert(H * NS * 32 == D && NCT == 8, "built for D = 128, 32-column head slices");
+  constexpr int TPB = 12 * NQ;                    // forward tiles per block (48; D = 96: 36)
+  constexpr int PSTEP = NCT / NPIECE;
   const int NT = TPB * p.L;
   const float sc = rsqrtf((float)DH) * CORA_LOG2E;
 
@@ -852,7 +990,7 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
   float* tB = tA + HT;
   float* tC = tB + HT;
   float* tD = tC + HT;
-  float* pb = tD + HT + 2 * H * 64;      // same carve-up as the block body: [b1 M | ln2 gamma D | ln2 beta D | b2 D]
+  float* pb = lds + Cfg::TILE_END + 2 * H * 64;      // same carve-up as the block body: [b1 M | ln2 gamma D | ln2 beta D | b2 D]
   constexpr int PB_LN2G = M, PB_LN2B = M + D, PB_B2 = M + 2 * D;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -868,7 +1006,9 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
     ldw = M; return p.W + p.oW2 + (long long)gg * D * M + (long long)(j - NQ) * TR * M + (long long)mt * D;
   };
   const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
-  float4 sr0, sr1, sr2, sr3;
+  const bool stg_ = (8 * (D / 4) >= 256) || tid < 8 * (D / 4);
+  float4 sr0, sr1, sr2, sr3, sr4, sr5;
+  (void)sr4; (void)sr5;
   int slot = 0;
   PREFETCH_ALL(0);
   WRITE_ALL(0);
@@ -907,7 +1047,9 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
         GEMM_D(k0 + 2 * NQ, xn, v)
       }
       float of[R];
-      if constexpr (NS > 1) {
+      if constexpr (NS == 3) {
+        wide2_attn_fwd_3<H, Cfg::NCS>(q, kk, v, of, tA, nullptr, nullptr, sc, w, i, grp);
+      } else if constexpr (NS > 1) {
         wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, nullptr, nullptr, sc, w, i, grp);
       } else {
 #pragma unroll
@@ -1010,21 +1152,18 @@ __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
 
 size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
 // P == 48: the edge layers (edge_path_wide, fused_wide_common.h) are written for the 4x4x3 patch of the sweep configs.
-// H = 4: heads of 32, one slice per head; H = 2 / 1: heads of 64 / 128 as two / four 32-column slices (sliced form)
-bool fused_wide2_supported(int N, int P, int D, int H, int M) { return N == 64 && D == 128 && (H == 4 || H == 2 || H == 1) && M == 4 * D && P == 48; }
+// D = 128: H = 4 (heads of 32, one slice per head), H = 2 / 1 (heads of 64 / 128 as two / four 32-column slices);
+// D = 96: H = 1 (three 32-column slices), H = 2 (heads of 48 as three 16-column slices).  Head dim 24 (D = 96, H = 4) is
+// not a whole number of column groups and stays on fused_wide.hip.
+bool fused_wide2_supported(int N, int P, int D, int H, int M) {
+  return N == 64 && M == 4 * D && P == 48 && ((D == 128 && (H == 4 || H == 2 || H == 1)) || (D == 96 && (H == 2 || H == 1)));
+}
 
 namespace {
-// dynamic LDS: 2 weight slots | 4 head tiles (sliced form: + 384 floats, see wide2_block_body) | lse, delta | parameter block
-constexpr size_t wide2_lds_bytes(int H) {
-  return (size_t)(2 * 32 * (128 + 4) + 4 * 64 * 36 + (H == 4 ? 0 : 384) + 2 * H * 64 + 512 + 4 * 128) * sizeof(float);
-}
-static_assert(2 * wide2_lds_bytes(2) <= 160 * 1024 && 2 * wide2_lds_bytes(1) <= 160 * 1024 && 2 * wide2_lds_bytes(4) <= 160 * 1024,
-              "two workgroups per CU");
-template <int H>
+template <int NCT, int H>
 int launch_fused_wide2_h(const FusedP& p, int L, hipStream_t st) {
   static bool attr[64] = {};
-  constexpr int NCT = 8;
-  constexpr size_t sm = wide2_lds_bytes(H);
+  constexpr size_t sm = (size_t)W2Cfg<NCT, H>::LDS_FLOATS * sizeof(float);
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)pc_block_wide2_kernel<NCT, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
@@ -1033,11 +1172,10 @@ int launch_fused_wide2_h(const FusedP& p, int L, hipStream_t st) {
   else hipLaunchKernelGGL((pc_block_wide2_kernel<NCT, H, false>), dim3((L + 1) * p.B), dim3(256), sm, st, p);
   return 0;
 }
-template <int H>
+template <int NCT, int H>
 int launch_chain_wide2_h(const FusedP& p, const float* xin, float* xout, long long stride, hipStream_t st) {
   static bool attr[64] = {};
-  constexpr int NCT = 8;
-  constexpr size_t sm = wide2_lds_bytes(H);
+  constexpr size_t sm = (size_t)W2Cfg<NCT, H>::LDS_FLOATS * sizeof(float);
   if (first_use_on_device(attr)) {
     if (hipFuncSetAttribute((const void*)pc_chain_wide2_kernel<NCT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return -1;
   }
@@ -1046,22 +1184,26 @@ int launch_chain_wide2_h(const FusedP& p, const float* xin, float* xout, long lo
 }
 }  // namespace
 
-int launch_fused_wide2(const FusedP& p, int L, hipStream_t st) {
-  switch (p.H) {
-    case 4: return launch_fused_wide2_h<4>(p, L, st);
-    case 2: return launch_fused_wide2_h<2>(p, L, st);
-    case 1: return launch_fused_wide2_h<1>(p, L, st);
+int launch_fused_wide2(const FusedP& p, int L, int D, hipStream_t st) {
+  switch (D * 8 + p.H) {
+    case 128 * 8 + 4: return launch_fused_wide2_h<8, 4>(p, L, st);
+    case 128 * 8 + 2: return launch_fused_wide2_h<8, 2>(p, L, st);
+    case 128 * 8 + 1: return launch_fused_wide2_h<8, 1>(p, L, st);
+    case 96 * 8 + 2: return launch_fused_wide2_h<6, 2>(p, L, st);
+    case 96 * 8 + 1: return launch_fused_wide2_h<6, 1>(p, L, st);
   }
   return -1;
 }
 
 // the L blocks of the status-"forward" chain for every image (see wide2_chain_body)
-int launch_chain_wide2(const FusedP& p, int L, const float* xin, float* xout, long long stride, hipStream_t st) {
+int launch_chain_wide2(const FusedP& p, int L, int D, const float* xin, float* xout, long long stride, hipStream_t st) {
   if (L < 1 || p.L != L) return -1;
-  switch (p.H) {
-    case 4: return launch_chain_wide2_h<4>(p, xin, xout, stride, st);
-    case 2: return launch_chain_wide2_h<2>(p, xin, xout, stride, st);
-    case 1: return launch_chain_wide2_h<1>(p, xin, xout, stride, st);
+  switch (D * 8 + p.H) {
+    case 128 * 8 + 4: return launch_chain_wide2_h<8, 4>(p, xin, xout, stride, st);
+    case 128 * 8 + 2: return launch_chain_wide2_h<8, 2>(p, xin, xout, stride, st);
+    case 128 * 8 + 1: return launch_chain_wide2_h<8, 1>(p, xin, xout, stride, st);
+    case 96 * 8 + 2: return launch_chain_wide2_h<6, 2>(p, xin, xout, stride, st);
+    case 96 * 8 + 1: return launch_chain_wide2_h<6, 1>(p, xin, xout, stride, st);
   }
   return -1;
 }

@@ -71,7 +71,8 @@ def _rel(a, b):
     ("12block", {"hidden_size": 128, "num_heads": 1}, 6),   # head dim 128 as four 32-column slices (wide2, sliced form)
     ("12block", {"hidden_size": 128, "num_heads": 2}, 6),   # head dim 64 as two slices
     ("12block", {"hidden_size": 96, "num_heads": 4}, 6),    # head dim 24: heads share a column group
-    ("12block", {"hidden_size": 96, "num_heads": 2}, 6),
+    ("12block", {"hidden_size": 96, "num_heads": 2}, 6),    # wide2: three 16-column slices per head
+    ("12block", {"hidden_size": 96, "num_heads": 1}, 6),    # wide2: three 32-column slices
 ])
 def test_fused_and_per_op_paths_agree_at_full_size(config, over, T):
     ca, mc, tc, x, h0 = _setup(200, mc_clip := 2000.0, config=config, **over)

@@ -49,7 +49,9 @@ CASES = {
     "d128_h4_P16": ((1, 32, 32), 4, 128, 4, 2, 2, 3),
     "d96_h2_P192": ((3, 64, 64), 8, 96, 2, 2, 2, 3),
     "n36_h2_ragged_chunk": ((3, 24, 24), 4, 32, 2, 2, 2, 3),   # N = 36: masked rows in the single-chunk attention kernels
-    "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),
+    "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),               # wide2: heads of 48 as three 16-column slices
+    "d96_h1_shallow": ((3, 32, 32), 4, 96, 1, 2, 3, 3),        # wide2: one head of 96 as three 32-column slices
+    "d96_h2_12block": ((3, 32, 32), 4, 96, 2, 12, 2, 3),
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
@@ -141,10 +143,11 @@ def test_wide_kernels_need_patch_dim_48(name, path):
     run_case(name, expect_path=path)
 
 
-@pytest.mark.parametrize("name", ["d128_h1_shallow", "d128_h2_shallow", "d128_h4_shallow"])
+@pytest.mark.parametrize("name", ["d128_h1_shallow", "d128_h2_shallow", "d128_h4_shallow", "d96_h2", "d96_h1_shallow"])
 def test_one_workgroup_wide_kernel_at_d128(name, monkeypatch):
-    """CORA_WIDE1=1: D = 128 on pc_block_wide_kernel (one workgroup per CU, K / V of all heads in LDS) instead of
-    pc_block_wide2_kernel -- the form the D = 96 points still run, kept reachable at D = 128 as the second implementation."""
+    """CORA_WIDE1=1: pc_block_wide_kernel (one workgroup per CU, K / V of all heads in LDS) instead of
+    pc_block_wide2_kernel -- the form head dim 24 (D = 96, H = 4) still runs, kept reachable everywhere else as the
+    second implementation."""
     monkeypatch.setenv("CORA_WIDE1", "1")
     run_case(name, expect_path="fused-wide")
 
@@ -245,7 +248,7 @@ def test_fused_pair_kernel_matches_four_wave_kernel_at_B25(H, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
-@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg", "wide2_h2", "wide2_h1_reg"])
+@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg", "wide2_h2", "wide2_h1_reg", "wide2_d96_h2", "wide2_d96_h1_gradnorm"])
 def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     """D = 64 fused path and the D = 128 / heads-of-32 kernel (wide2): inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
     of step t + 1 as it loads its rows (FusedP::lazy, vodes / momentum / gradients ping-ponging between two arena
@@ -255,7 +258,7 @@ def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     updates (T - 1), and across two batches (the second replays the captured graph)."""
     import cora_amd as ca
     D, H = {"h1": (64, 1), "h2_gradnorm": (64, 2), "h4_reg": (64, 4), "wide2": (128, 4), "wide2_gradnorm_reg": (128, 4),
-            "wide2_h2": (128, 2), "wide2_h1_reg": (128, 1)}[variant]
+            "wide2_h2": (128, 2), "wide2_h1_reg": (128, 1), "wide2_d96_h2": (96, 2), "wide2_d96_h1_gradnorm": (96, 1)}[variant]
     kw = dict(clip_h=3.0, clip_w=0.5)
     if "gradnorm" in variant:
         kw.update(use_grad_norm=True, grad_norm_target=2.0)
