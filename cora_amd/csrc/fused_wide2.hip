@@ -512,9 +512,11 @@ struct W2Cfg {
 // The macros name locals both bodies define: tile_src (tile index -> source pointer and row stride), the
 // staging registers sr0..sr3, trow / tcol, wbuf, slot, NT (tiles this workgroup walks through) and the
 // tile geometry constants.
-// (D = 96: a tile row is 24 float4, so 192 threads -- waves 0..2 -- stage 8 rows per piece and wave 3 stages nothing)
-#define PF_ONE(J, REG, SRC, LDW) if (stg_) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
-#define PB_ONE(J, REG, WB) if (stg_) lds_st4((WB) + 8 * (J) * LD, REG);
+// (D = 96: a tile row is 24 float4, so 192 threads -- waves 0..2 -- cover the 8 rows of a piece; wave 3 repeats wave 2's
+// part, the same values to the same LDS addresses: a per-lane guard instead put exec-mask code around each of the 12
+// pieces of a stage, between the MFMAs)
+#define PF_ONE(J, REG, SRC, LDW) REG = *reinterpret_cast<const float4*>((SRC) + (long long)(8 * (J)) * (LDW) + (unsigned)(trow * (LDW) + tcol));
+#define PB_ONE(J, REG, WB) lds_st4((WB) + 8 * (J) * LD, REG);
 #define PREFETCH_ALL(K)                                                                           \
   do {                                                                                            \
     int ld_; const float* s_ = tile_src((K), ld_);                                                \
@@ -676,8 +678,8 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     const int j = k - 21 * NQ;
     ldw = 3 * D; return WqkvT + (long long)(j % NQ) * TR * 3 * D + (long long)(j / NQ) * D;
   };
-  const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
-  const bool stg_ = (8 * (D / 4) >= 256) || tid < 8 * (D / 4);
+  const int tst = (8 * (D / 4) >= 256 || tid < 8 * (D / 4)) ? tid : tid - 64;     // staging thread index (see PF_ONE)
+  const int trow = tst / (D / 4), tcol = 4 * (tst % (D / 4));
   float4 sr0, sr1, sr2, sr3, sr4, sr5;
   (void)sr4; (void)sr5;
   int slot = SLOT0;
@@ -1005,8 +1007,8 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
     if (j < NQ) { ldw = D; return p.W + p.oW1 + (long long)gg * M * D + ((long long)mt * D + j * TR) * D; }
     ldw = M; return p.W + p.oW2 + (long long)gg * D * M + (long long)(j - NQ) * TR * M + (long long)mt * D;
   };
-  const int trow = tid / (D / 4), tcol = 4 * (tid % (D / 4));
-  const bool stg_ = (8 * (D / 4) >= 256) || tid < 8 * (D / 4);
+  const int tst = (8 * (D / 4) >= 256 || tid < 8 * (D / 4)) ? tid : tid - 64;     // staging thread index (see PF_ONE)
+  const int trow = tst / (D / 4), tcol = 4 * (tst % (D / 4));
   float4 sr0, sr1, sr2, sr3, sr4, sr5;
   (void)sr4; (void)sr5;
   int slot = 0;
