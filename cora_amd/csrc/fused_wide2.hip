@@ -475,19 +475,138 @@ __device__ __forceinline__ void wide2_attn_bwd_3(float* tz, const float* lse, fl
   }
 }
 
+// ---- D = 96, four heads of 24 ---------------------------------------------------------------------------------
+// Head h lives in column groups c0 = h + h / 2 and c0 + 1: one whole group and HALF of the group it shares with its
+// neighbour (even h: lane groups 0, 1 of the second group; odd h: lane groups 2, 3 of the first).  Its tiles are the
+// 32-column slice of those two groups, as for heads of 32; the neighbour's 8 columns in them are harmless because
+// every product either multiplies them with a REGISTER operand that is zeroed on the lanes that hold those columns
+// (scores: S, dP) or produces results for them that are dropped lane by lane (O, dq, dK, dV).
+__device__ __forceinline__ void h24_masked(const float* src8, float* dst8, int h, int grp) {
+  const int pg = (h & 1) ? 0 : 1;
+  const bool valid = (h & 1) ? (grp >= 2) : (grp < 2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst8[k] = ((k >> 2) == pg && !valid) ? 0.f : src8[k];
+}
+// results of a slice into the row registers: the whole group as it is, the shared group on this head's lanes only
+// (an even head writes the shared group first, garbage on the other lanes; its odd neighbour then takes its lanes)
+__device__ __forceinline__ void h24_merge(const float* out8, float* dst8, int h, int grp) {
+  const int pg = (h & 1) ? 0 : 1;
+  const bool valid = (h & 1) ? (grp >= 2) : (grp < 2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst8[k] = ((k >> 2) == pg && (h & 1) && !valid) ? dst8[k] : out8[k];
+}
+// ... and into a stash row: the shared group's float4 is stored by the lanes that own it
+__device__ __forceinline__ void h24_store(const float* f8, float* base, int h, int grp) {   // base = row pointer + 16 c0
+  const int pg = (h & 1) ? 0 : 1;
+  const bool valid = (h & 1) ? (grp >= 2) : (grp < 2);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c != pg || valid) *reinterpret_cast<float4*>(base + 16 * c + 4 * grp) = make_float4(f8[4 * c], f8[4 * c + 1], f8[4 * c + 2], f8[4 * c + 3]);
+}
+__device__ __forceinline__ void wide2_attn_fwd_h24(const float* q, const float* kk, const float* v, float* of, float* tA, float* tB,
+                                                   float* tC, float* tD, float* lse, float* st_p, float sc, int w, int i, int grp) {
+#pragma unroll
+  for (int hp = 0; hp < 4; hp += 2) {
+    const int ca = hp + hp / 2, cb = (hp + 1) + (hp + 1) / 2;     // first column group of the two heads' slices
+    __syncthreads();                   // the previous round's tiles are no longer read
+    put_slice<W2_LDH, 2>(kk + 4 * ca, tA, w, i, grp);
+    put_slice_t<W2_LDT, 2>(v + 4 * ca, tB, w, i, grp);
+    put_slice<W2_LDH, 2>(kk + 4 * cb, tC, w, i, grp);
+    put_slice_t<W2_LDT, 2>(v + 4 * cb, tD, w, i, grp);
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int h = hp + hh, c0 = hh ? cb : ca;
+      const float* tK = hh ? tC : tA;
+      const float* tV = hh ? tD : tB;
+      float qm[8], o8[8], pf[16];
+      h24_masked(q + 4 * c0, qm, h, grp);
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+      gemm_hd<W2_LDH, 2>(tK, qm, sa, i, grp);                     // S[key][q] over this head's 24 columns
+      const float l2 = softmax_keys(sa, pf, sc);
+      if (lse && grp == 0) lse[64 * h + 16 * w + i] = l2;
+      if (st_p) store_row<4>(pf, st_p + 64 * h, grp);
+      accum_t<W2_LDT, 2>(tV, pf, o8, 1.0f, i, grp);
+      h24_merge(o8, of + 4 * c0, h, grp);
+    }
+  }
+}
+// six tiles per head as for heads of 32 (V, Q, dO row-major; K, Q, dO transposed), at the addresses the caller passes
+__device__ __forceinline__ void wide2_attn_bwd_h24(float* bV, float* bKT, float* bQ, float* bdO, float* bQT, float* bdOT, const float* lse,
+                                                   float* delta, const float* st_q, const float* st_k, const float* st_v,
+                                                   const float* st_p, float* st_dkv, const float* dof, float* dy, float sc,
+                                                   float qscale, int w, int i, int grp) {
+  constexpr int D = 96;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int c0 = h + h / 2;
+    float ks[8], vs[8], pf[16], dp[16], dom[8];
+    {
+      float qs[8];
+      load_slice<2>(ks, st_k + 16 * c0, grp);
+      load_slice<2>(vs, st_v + 16 * c0, grp);
+      load_slice<2>(qs, st_q + 16 * c0, grp);
+      load_row<4>(pf, st_p + 64 * h, grp);
+      __syncthreads();                 // the previous head's tiles (and weight tile 21 NQ - 1) are no longer read
+      put_slice<W2_LDH, 2>(vs, bV, w, i, grp);
+      put_slice_t<W2_LDT, 2>(ks, bKT, w, i, grp);
+      put_slice<W2_LDH, 2>(qs, bQ, w, i, grp);
+      put_slice<W2_LDH, 2>(dof + 4 * c0, bdO, w, i, grp);
+      put_slice_t<W2_LDT, 2>(qs, bQT, w, i, grp);
+      put_slice_t<W2_LDT, 2>(dof + 4 * c0, bdOT, w, i, grp);
+    }
+    __syncthreads();
+    {
+      // own queries: dP[key][q] = V[key] . dO[q] over the head's columns, delta, dS, dq
+      h24_masked(dof + 4 * c0, dom, h, grp);
+      f32x4 sa[4];
+      zero_acc<4>(sa);
+      gemm_hd<W2_LDH, 2>(bV, dom, sa, i, grp);
+      unpack_at<4>(sa, dp, 0);
+      float dl = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dl += pf[k] * dp[k];
+      dl = grp_sum(dl);
+      if (grp == 0) delta[64 * h + 16 * w + i] = dl;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dp[k] = pf[k] * (dp[k] - dl);
+      float o8[8];
+      accum_t<W2_LDT, 2>(bKT, dp, o8, qscale, i, grp);
+      h24_merge(o8, dy + 4 * c0, h, grp);                          // dq (into dy)
+    }
+    __syncthreads();                   // delta of all 64 queries visible
+    {
+      // own keys: S and dP recomputed with the key on the lane; dV = P^T dO, dK = dS^T Q
+      float sp[16], km[8], vm[8], o8[8];
+      h24_masked(ks, km, h, grp);
+      h24_masked(vs, vm, h, grp);
+      f32x4 sa[4];
+      zero_acc<4>(sa); gemm_hd<W2_LDH, 2>(bQ, km, sa, i, grp); unpack_at<4>(sa, sp, 0);      // S[q][key]
+      zero_acc<4>(sa); gemm_hd<W2_LDH, 2>(bdO, vm, sa, i, grp); unpack_at<4>(sa, dp, 0);     // dP[q][key]
+      p_ds_keys(sp, dp, lse + 64 * h, delta + 64 * h, sc, grp);
+      accum_t<W2_LDT, 2>(bdOT, sp, o8, 1.0f, i, grp);       // dV
+      h24_store(o8, st_dkv + D + 16 * c0, h, grp);
+      accum_t<W2_LDT, 2>(bQT, dp, o8, qscale, i, grp);      // dK
+      h24_store(o8, st_dkv + 16 * c0, h, grp);
+    }
+  }
+}
+
 // LDS carve-up shared by the bodies and the launchers (floats): 2 weight slots | head-tile area | lse, delta | parameters
 template <int NCT, int H>
 struct W2Cfg {
   static constexpr int D = 16 * NCT, M = 4 * D, DH = D / H;
+  static constexpr bool H24 = NCT == 6 && H == 4;                // heads of 24: lane-masked 32-column slices (wide2_attn_*_h24)
   static constexpr int SW = (NCT == 6 && H == 2) ? 16 : 32;      // slice width: 32 columns, 16 for heads of 48
-  static constexpr int NS = DH / SW, NCS = SW / 16;
+  static constexpr int NS = H24 ? 1 : DH / SW, NCS = SW / 16;
   static constexpr int NOT = NCT == 6 ? 3 : 2;                  // 16-row output groups of a weight tile (32 rows; D = 96: 48)
   static constexpr int SLOT = 16 * NOT * (D + 4), HT = 64 * 36, TS = 64 * (SW + 4);
   static constexpr int FWD_END = 2 * SLOT + 4 * HT;              // forward: four head-tile slots behind the weight slots
   static constexpr int BWD_END = NS > 1 ? SLOT + 6 * TS : 0;     // sliced backward: six slots from weight slot 1 on
   static constexpr int TILE_END = FWD_END > BWD_END ? FWD_END : BWD_END;
   static constexpr int LDS_FLOATS = TILE_END + 2 * H * 64 + M + 4 * D;
-  static_assert(NS * SW == DH && (NCT == 8 ? (H == 4 || H == 2 || H == 1) : (NCT == 6 && (H == 2 || H == 1))), "shape not built");
+  static_assert((H24 || NS * SW == DH) && (NCT == 8 ? (H == 4 || H == 2 || H == 1) : (NCT == 6 && (H == 4 || H == 2 || H == 1))), "shape not built");
   static_assert(2 * LDS_FLOATS * 4 <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -726,7 +845,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     W2STAMP(2);
     // attention, two heads per round: K_h, V_h slices of all 64 tokens in the head tiles
     float of[R];
-    if constexpr (NS == 3) {
+    if constexpr (Cfg::H24) {
+      wide2_attn_fwd_h24(q, kk, v, of, tA, tB, tC, tD, rowc, st_p, sc, w, i, grp);
+    } else if constexpr (NS == 3) {
       wide2_attn_fwd_3<H, Cfg::NCS>(q, kk, v, of, tA, rowc, st_p, sc, w, i, grp);
     } else if constexpr (NS > 1) {
       wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, rowc, st_p, sc, w, i, grp);
@@ -876,7 +997,9 @@ __device__ __forceinline__ void wide2_block_body(const FusedP& p, float* lds, in
     float* bQT = bdO + HT;
     float* bdOT = bQT + 32 * LDT;
     float* delta = rowc + 64 * H;
-    if constexpr (NS == 3) {
+    if constexpr (Cfg::H24) {
+      wide2_attn_bwd_h24(bV, bKT, bQ, bdO, bQT, bdOT, rowc, delta, st_q, st_k, st_v, st_p, st_dkv, dof, dy, sc, qscale, w, i, grp);
+    } else if constexpr (NS == 3) {
       wide2_attn_bwd_3<H, Cfg::NCS>(wbuf + SLOT, rowc, delta, st_q, st_k, st_v, st_p, st_dkv, dof, dy, sc, qscale, w, i, grp);
     } else if constexpr (NS > 1) {
       // heads of 64 / 128: the same tiles, 32-column slice by slice, scores accumulated across a head's slices
@@ -1049,7 +1172,9 @@ __device__ __forceinline__ void wide2_chain_body(const FusedP& p, float* lds, in
         GEMM_D(k0 + 2 * NQ, xn, v)
       }
       float of[R];
-      if constexpr (NS == 3) {
+      if constexpr (Cfg::H24) {
+        wide2_attn_fwd_h24(q, kk, v, of, tA, tB, tC, tD, nullptr, nullptr, sc, w, i, grp);
+      } else if constexpr (NS == 3) {
         wide2_attn_fwd_3<H, Cfg::NCS>(q, kk, v, of, tA, nullptr, nullptr, sc, w, i, grp);
       } else if constexpr (NS > 1) {
         wide2_attn_fwd_sliced<H>(q, kk, v, of, tA, tB, tC, tD, nullptr, nullptr, sc, w, i, grp);
@@ -1155,10 +1280,10 @@ __global__ __launch_bounds__(256, 2) void pc_block_wide2_kernel(FusedP p) {
 size_t fused_wide2_stash_floats_per_row(int D, int H) { return (size_t)H * 64 + 3 * (size_t)D; }
 // P == 48: the edge layers (edge_path_wide, fused_wide_common.h) are written for the 4x4x3 patch of the sweep configs.
 // D = 128: H = 4 (heads of 32, one slice per head), H = 2 / 1 (heads of 64 / 128 as two / four 32-column slices);
-// D = 96: H = 1 (three 32-column slices), H = 2 (heads of 48 as three 16-column slices).  Head dim 24 (D = 96, H = 4) is
-// not a whole number of column groups and stays on fused_wide.hip.
+// D = 96: H = 1 (three 32-column slices), H = 2 (heads of 48 as three 16-column slices), H = 4 (heads of 24: one and a
+// half column groups, lane-masked 32-column slices).
 bool fused_wide2_supported(int N, int P, int D, int H, int M) {
-  return N == 64 && M == 4 * D && P == 48 && ((D == 128 && (H == 4 || H == 2 || H == 1)) || (D == 96 && (H == 2 || H == 1)));
+  return N == 64 && M == 4 * D && P == 48 && (D == 128 || D == 96) && (H == 4 || H == 2 || H == 1);
 }
 
 namespace {
@@ -1191,6 +1316,7 @@ int launch_fused_wide2(const FusedP& p, int L, int D, hipStream_t st) {
     case 128 * 8 + 4: return launch_fused_wide2_h<8, 4>(p, L, st);
     case 128 * 8 + 2: return launch_fused_wide2_h<8, 2>(p, L, st);
     case 128 * 8 + 1: return launch_fused_wide2_h<8, 1>(p, L, st);
+    case 96 * 8 + 4: return launch_fused_wide2_h<6, 4>(p, L, st);
     case 96 * 8 + 2: return launch_fused_wide2_h<6, 2>(p, L, st);
     case 96 * 8 + 1: return launch_fused_wide2_h<6, 1>(p, L, st);
   }
@@ -1204,6 +1330,7 @@ int launch_chain_wide2(const FusedP& p, int L, int D, const float* xin, float* x
     case 128 * 8 + 4: return launch_chain_wide2_h<8, 4>(p, xin, xout, stride, st);
     case 128 * 8 + 2: return launch_chain_wide2_h<8, 2>(p, xin, xout, stride, st);
     case 128 * 8 + 1: return launch_chain_wide2_h<8, 1>(p, xin, xout, stride, st);
+    case 96 * 8 + 4: return launch_chain_wide2_h<6, 4>(p, xin, xout, stride, st);
     case 96 * 8 + 2: return launch_chain_wide2_h<6, 2>(p, xin, xout, stride, st);
     case 96 * 8 + 1: return launch_chain_wide2_h<6, 1>(p, xin, xout, stride, st);
   }

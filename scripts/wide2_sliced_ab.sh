@@ -1,6 +1,6 @@
 # A/B of the two-workgroup kernel (pc_block_wide2, sliced heads) against the one-workgroup kernel (CORA_WIDE1=1) on the
 # grid points the former took over in round 3; results in gpurun_out/w2ab_D<D>_H<H>_w<0|1>.json
-for DH in "128 1" "128 2" "96 1" "96 2" "128 4"; do
+for DH in "128 1" "128 2" "96 1" "96 2" "96 4" "128 4"; do
   set -- $DH
   for W in 0 1; do
     if [ $W = 1 ]; then export CORA_WIDE1=1; else unset CORA_WIDE1; fi

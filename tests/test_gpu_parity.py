@@ -52,7 +52,8 @@ CASES = {
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),               # wide2: heads of 48 as three 16-column slices
     "d96_h1_shallow": ((3, 32, 32), 4, 96, 1, 2, 3, 3),        # wide2: one head of 96 as three 32-column slices
     "d96_h2_12block": ((3, 32, 32), 4, 96, 2, 12, 2, 3),
-    "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),
+    "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),      # wide2: heads of 24 = one and a half column groups, lane-masked slices
+    "d96_h4_12block": ((3, 32, 32), 4, 96, 4, 12, 3, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
     # the row-tile fused kernels (fused_rows.hip: D = 64, B*N a multiple of 64, any sequence length) around attn.hip
@@ -143,11 +144,10 @@ def test_wide_kernels_need_patch_dim_48(name, path):
     run_case(name, expect_path=path)
 
 
-@pytest.mark.parametrize("name", ["d128_h1_shallow", "d128_h2_shallow", "d128_h4_shallow", "d96_h2", "d96_h1_shallow"])
+@pytest.mark.parametrize("name", ["d128_h1_shallow", "d128_h2_shallow", "d128_h4_shallow", "d96_h2", "d96_h1_shallow", "d96_h4_headdim24"])
 def test_one_workgroup_wide_kernel_at_d128(name, monkeypatch):
     """CORA_WIDE1=1: pc_block_wide_kernel (one workgroup per CU, K / V of all heads in LDS) instead of
-    pc_block_wide2_kernel -- the form head dim 24 (D = 96, H = 4) still runs, kept reachable everywhere else as the
-    second implementation."""
+    pc_block_wide2_kernel -- round 2's kernel for these shapes, kept reachable as the second implementation."""
     monkeypatch.setenv("CORA_WIDE1", "1")
     run_case(name, expect_path="fused-wide")
 
@@ -248,7 +248,7 @@ def test_fused_pair_kernel_matches_four_wave_kernel_at_B25(H, monkeypatch):
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
-@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg", "wide2_h2", "wide2_h1_reg", "wide2_d96_h2", "wide2_d96_h1_gradnorm"])
+@pytest.mark.parametrize("variant", ["h1", "h2_gradnorm", "h4_reg", "wide2", "wide2_gradnorm_reg", "wide2_h2", "wide2_h1_reg", "wide2_d96_h2", "wide2_d96_h1_gradnorm", "wide2_d96_h4_reg"])
 def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     """D = 64 fused path and the D = 128 / heads-of-32 kernel (wide2): inside a T-step loop the momentum-SGD update of step t is applied by the inference launch
     of step t + 1 as it loads its rows (FusedP::lazy, vodes / momentum / gradients ping-ponging between two arena
@@ -258,7 +258,7 @@ def test_deferred_vode_update_matches_update_kernel(variant, T, monkeypatch):
     updates (T - 1), and across two batches (the second replays the captured graph)."""
     import cora_amd as ca
     D, H = {"h1": (64, 1), "h2_gradnorm": (64, 2), "h4_reg": (64, 4), "wide2": (128, 4), "wide2_gradnorm_reg": (128, 4),
-            "wide2_h2": (128, 2), "wide2_h1_reg": (128, 1), "wide2_d96_h2": (96, 2), "wide2_d96_h1_gradnorm": (96, 1)}[variant]
+            "wide2_h2": (128, 2), "wide2_h1_reg": (128, 1), "wide2_d96_h2": (96, 2), "wide2_d96_h1_gradnorm": (96, 1), "wide2_d96_h4_reg": (96, 4)}[variant]
     kw = dict(clip_h=3.0, clip_w=0.5)
     if "gradnorm" in variant:
         kw.update(use_grad_norm=True, grad_norm_target=2.0)
