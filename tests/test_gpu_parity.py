@@ -152,6 +152,44 @@ def test_one_workgroup_wide_kernel_at_d128(name, monkeypatch):
     run_case(name, expect_path="fused-wide")
 
 
+@pytest.mark.parametrize("name", ["cfg2_shape_B4", "d128_h2_shallow", "d96_h4_headdim24", "rows_n256_h2_L3", "tiny_2block_h2"])
+def test_profile_step_leaves_the_trajectory_alone(name):
+    """cora_profile_step (bench.py's roofline leg) warms the clocks with inference steps at step size 0 and times the
+    block kernel as a burst of identical launches: vodes, momentum and the next batches must come out as if it had never
+    run -- on every kernel path (D = 64 fused with the deferred update, wide2, row-tile, per-op)."""
+    import ctypes as C
+    import cora_amd as ca
+    from cora_amd import _lib
+    shape, p, D, H, L, B, T = CASES[name]
+    case = make_case(shape, p, D, H, L, B, seed=77, clip_h=3.0, clip_w=0.5)
+    res = []
+    for prof in (False, True):
+        model, ow, oh = build_model(case)
+        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh)]
+        if prof:
+            lib, ctx, cap = _lib.load(), model._ctx, 16
+            names = C.create_string_buffer(32 * cap)
+            launches, nout = (C.c_int * cap)(), C.c_int()
+            ms, fl, by = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+            _lib.check(lib.cora_profile_step(ctx, cap, names, launches, ms, fl, by, C.byref(nout)), ctx)
+            assert nout.value > 0 and sum(launches[k] for k in range(nout.value)) > 0
+            assert all(np.isfinite(ms[k]) and ms[k] >= 0 for k in range(nout.value))
+        outs.append(ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh))
+        tot, per = ca.step_energies(model, T)
+        res.append(dict(outs=outs, tot=tot, per=per, h=[model.vodes[l].h.get() for l in range(L + 2)], w=model.get_weights()))
+        model.close()
+    a, b = res
+    assert relerr(a["tot"], b["tot"]) <= 1e-6 and relerr(a["per"], b["per"]) <= 1e-6
+    for oa, ob in zip(a["outs"], b["outs"]):
+        assert oa[0] == pytest.approx(ob[0], rel=1e-6) and oa[1] == pytest.approx(ob[1], rel=1e-6) and oa[4] == pytest.approx(ob[4], rel=1e-5)
+    for l in range(L + 2):
+        assert relerr(a["h"][l], b["h"][l]) <= 2e-6, l
+    # two AdamW steps: split-K float atomics make dE/dW differ run to run at the 1e-7 level and AdamW's division by
+    # sqrt(nu) + eps amplifies that on near-zero entries (DESIGN.md section 4) -- a leak of profile state would be O(1)
+    for k in a["w"]:
+        assert relerr(a["w"][k], b["w"][k]) <= 5e-5, k
+
+
 def test_regularisers_and_clipping():
     # l1/l2 vode regularisers on, and clip thresholds low enough that both clips trigger
     run_case("tiny_2block_h2", l1=1e-3, l2=1e-3, clip_h=5.0, clip_w=0.5)
