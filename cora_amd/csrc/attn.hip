@@ -371,23 +371,31 @@ __global__ __launch_bounds__(64 * NW, DH <= 48 ? (NW == 8 ? 3 : 4) : 1) void att
 
   const bool wave_active = rb * 16 * NW + 16 * w < N;
   constexpr bool PRE = (NW == 8);
+  float rc_l = 0.f, rc_d = 0.f;            // PRE: lse2 / delta of the next chunk's queries, prefetched with its rows
+  auto load_rowc = [&](int qn) {
+    if (threadIdx.x < CH) {
+      const int q = qn + threadIdx.x;
+      const long long ri = ((long long)img * N + q) * H + h;
+      rc_l = (q < N) ? lse2[ri] : 0.f;
+      rc_d = (q < N) ? delta[ri] : 0.f;
+    }
+  };
   StageF<DH, 64 * NW> stg;
-  if (PRE) stg.load(Q, ld, dOp, D, 0, N);
+  if (PRE) { stg.load(Q, ld, dOp, D, 0, N); load_rowc(0); }
   for (int q0 = 0; q0 < N; q0 += CH) {
     __syncthreads();
     if (PRE) stg.store(sm.s1, sm.s2);
     else {
       stage_rows<DH, 64 * NW>(sm.s1, Q, ld, q0, N);
       stage_rows<DH, 64 * NW>(sm.s2, dOp, D, q0, N);
+      load_rowc(q0);
     }
     if (threadIdx.x < CH) {
-      int q = q0 + threadIdx.x;
-      long long ri = ((long long)img * N + q) * H + h;
-      sm.rowc[threadIdx.x] = (q < N) ? lse2[ri] : 0.f;
-      sm.rowc[CH + threadIdx.x] = (q < N) ? delta[ri] : 0.f;
+      sm.rowc[threadIdx.x] = rc_l;
+      sm.rowc[CH + threadIdx.x] = rc_d;
     }
     __syncthreads();
-    if (PRE && q0 + CH < N) stg.load(Q, ld, dOp, D, q0 + CH, N);
+    if (PRE && q0 + CH < N) { stg.load(Q, ld, dOp, D, q0 + CH, N); load_rowc(q0 + CH); }
     if (!wave_active) continue;
     for_valid_tiles((N - q0 + 15) >> 4, [&](auto nv) {
       constexpr int NVT = decltype(nv)::value;
@@ -583,18 +591,27 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_fused_kernel(const float*
   for (int ct = 0; ct < NCT; ++ct) { dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const bool key_ok = krow < N;
 
+  // lse2 / delta of a chunk's 64 queries travel with its Q / dO rows: fetched into two registers of wave 0 a chunk ahead.
+  // (Loaded between the two barriers they left all eight waves waiting for one global-load latency per chunk.)
+  float rc_l = 0.f, rc_d = 0.f;
+  auto load_rowc = [&](int qn) {
+    if (threadIdx.x < CH) {
+      const long long ri = ((long long)img * N + qn + threadIdx.x) * H + h;
+      rc_l = lse2[ri]; rc_d = delta[ri];
+    }
+  };
   StageF<DH, 64 * NW> stg;
   stg.load(Q, ld, dOp, D, 0, N);
+  load_rowc(0);
   for (int q0 = 0; q0 < N; q0 += CH) {
     __syncthreads();                         // the previous chunk's s1 / s2 / sT are no longer read
     stg.store(sm.s1, sm.s2);
     if (threadIdx.x < CH) {
-      const long long ri = ((long long)img * N + q0 + threadIdx.x) * H + h;
-      sm.rowc[threadIdx.x] = lse2[ri];
-      sm.rowc[CH + threadIdx.x] = delta[ri];
+      sm.rowc[threadIdx.x] = rc_l;
+      sm.rowc[CH + threadIdx.x] = rc_d;
     }
     __syncthreads();
-    if (q0 + CH < N) stg.load(Q, ld, dOp, D, q0 + CH, N);
+    if (q0 + CH < N) { stg.load(Q, ld, dOp, D, q0 + CH, N); load_rowc(q0 + CH); }
     {
       f32x4 S[4], dP[4];
       score_tiles<DH>(S, sm.s1, kf, c, grp);     // S[q][key]
