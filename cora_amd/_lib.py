@@ -65,6 +65,7 @@ SIGNATURES = {
     "cora_comm_init": (C.c_int, [_P, _P, _SZ, C.c_int, C.c_int]),
     "cora_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cora_step_dist": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_float, C.c_int, C.POINTER(CoraStepOut)]),
+    "cora_step_ipc_dist": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(CoraStepOut)]),
     "cora_dist_prepare": (C.c_int, [_P, C.c_int, C.c_int]),
     "cora_dist_set_eager": (C.c_int, [_P, C.c_int]),
     "cora_dist_mode": (C.c_int, [_P]),

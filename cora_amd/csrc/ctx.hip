@@ -1693,8 +1693,25 @@ int cora_infer_end(cora_ctx* c, cora_step_out* out) {
 
 // MODE 1 of train_on_batch (update_weights_every_inference_step, :418-439): every iteration is one
 // vode step followed by one weight step at the updated vodes; see include/cora_hip.h
+// dist: the data-parallel form (cora_step_ipc_dist) -- exact != 0: the sums-of-squares row of every vode step summed over
+// the ranks between its two halves; dE/dW summed over the ranks before every weight step, scale 1 / (B * world)
+static int step_ipc_impl(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, const float* eta_w, cora_step_out* out,
+                         bool dist, bool exact);
 int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, const float* eta_w, cora_step_out* out) {
+  return step_ipc_impl(c, x, x_on_device, T, eta_h, eta_w, out, false, false);
+}
+#define NCHECK(call)                                                                                   \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      c->err = std::string(#call " failed: ") + g_rccl.GetErrorString(r_);                             \
+      return -5;                                                                                       \
+    }                                                                                                  \
+  } while (0)
+static int step_ipc_impl(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, const float* eta_w, cora_step_out* out,
+                         bool dist, bool exact) {
   if (!c) return -1;
+  if (dist && !c->comm) FAIL(-1, "cora_step_ipc_dist: call cora_comm_init first");
   if (T < 1 || T > c->Tmax) FAIL(-1, "T out of range (1..max_T)");
   if (!eta_h || !eta_w) FAIL(-1, "eta_h / eta_w is NULL");
   HCHECK(hipSetDevice(c->device));
@@ -1716,10 +1733,18 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
   c->last_T = T;
   HCHECK(hipEventRecord(c->ev0, c->st));
   zero_infer_logs(c, T);
+  const float scale_by = 1.0f / ((float)c->B * (dist ? (float)c->comm_world : 1.0f));
+  const size_t nrow = (size_t)(L + 2) * 8;
   for (int t = 0; t < T && !rc; ++t) {
-    rc = infer_step(c, t);                                                     // :421-424
+    rc = infer_grad_step(c, t);                                                // :421-424
+    if (!rc && dist && exact) {
+      double* row = c->sumsq + (long long)t * nrow;
+      NCHECK(g_rccl.AllReduce(row, row, nrow, ncclDouble, ncclSum, c->comm, c->st));
+    }
+    if (!rc) rc = infer_update_step(c, t);
     if (!rc) rc = enqueue_wgrad(c);                                            // :426-427
-    if (!rc) rc = enqueue_adamw(c, 1.0f / (float)c->B, c->hyp_dev + 4 + 4 * t);  // :428
+    if (!rc && dist) NCHECK(g_rccl.AllReduce(c->dW, c->dW, c->nW, ncclFloat, ncclSum, c->comm, c->st));
+    if (!rc) rc = enqueue_adamw(c, scale_by, c->hyp_dev + 4 + 4 * t);          // :428
     if (!rc) c->adam_count += 1;
   }
   if (rc) return rc;
@@ -1750,15 +1775,6 @@ int cora_step_ipc(cora_ctx* c, const float* x, int x_on_device, int T, const flo
 
 // ---- data parallelism with RCCL bound inside the library ---------------------------------------------
 // (see include/cora_hip.h: cora_comm_unique_id / cora_comm_init / cora_step_dist)
-#define NCHECK(call)                                                                                   \
-  do {                                                                                                 \
-    ncclResult_t r_ = (call);                                                                          \
-    if (r_ != ncclSuccess) {                                                                           \
-      c->err = std::string(#call " failed: ") + g_rccl.GetErrorString(r_);                             \
-      return -5;                                                                                       \
-    }                                                                                                  \
-  } while (0)
-
 int cora_comm_unique_id(void* id, size_t nbytes) {
   if (!id || nbytes != sizeof(ncclUniqueId)) { g_create_err = "unique id buffer must be 128 bytes"; return -1; }
   if (const char* e = rccl_load()) { g_create_err = e; return -5; }
@@ -1941,6 +1957,11 @@ int cora_step_dist(cora_ctx* c, const float* x, int x_on_device, int T, const fl
     out->train_mse = ho[nslot + (L + 3)] / (double)c->n0;
   }
   return 0;
+}
+
+int cora_step_ipc_dist(cora_ctx* c, const float* x, int x_on_device, int T, const float* eta_h, const float* eta_w,
+                       int exact_clip, cora_step_out* out) {
+  return step_ipc_impl(c, x, x_on_device, T, eta_h, eta_w, out, true, exact_clip != 0);
 }
 
 int cora_wgrad_buffer(cora_ctx* c, void** dev, size_t* n) {

@@ -488,11 +488,15 @@ def train_on_batch(T: int, x, *, model: TransformerDecoder, optim_w: Optim, opti
     model._x_host = x.copy()
     model._grad_options(not model.config.update_weights_every_inference_step)
     if model.config.update_weights_every_inference_step:      # MODE 1 (iPC), reference :418-439
-        if model._dp is not None:
-            raise NotImplementedError("iPC mode is single-GPU (one dE/dW all-reduce per inference step is not built; "
-                                      "DESIGN.md section 5)")
+        if model._dp is not None and not model._dp.in_library:
+            raise NotImplementedError("iPC mode under data parallelism needs DataParallel(backend='rccl'): the dE/dW "
+                                      "all-reduce of every inference step runs inside the library (cora_step_ipc_dist)")
         eta_ws = np.array([lr_at(rw.base.learning_rate, optim_w.count + t) for t in range(T)], dtype=np.float32)
-        _lib.check(lib.cora_step_ipc(ctx, _fptr(x), 0, T, _fptr(eta_h), _fptr(eta_ws), C.byref(out)), ctx)
+        if model._dp is not None:
+            _lib.check(lib.cora_step_ipc_dist(ctx, _fptr(x), 0, T, _fptr(eta_h), _fptr(eta_ws),
+                                              int(model._dp.exact_clip), C.byref(out)), ctx)
+        else:
+            _lib.check(lib.cora_step_ipc(ctx, _fptr(x), 0, T, _fptr(eta_h), _fptr(eta_ws), C.byref(out)), ctx)
         optim_w.count += T - 1                               # the common `count += 1` below makes it T
     elif model._dp is None:
         _lib.check(lib.cora_step(ctx, _fptr(x), 0, T, _fptr(eta_h), C.c_float(eta_w), C.byref(out)), ctx)

@@ -190,6 +190,12 @@ int cora_comm_init(cora_ctx* ctx, const void* id128, size_t nbytes, int rank, in
 int cora_comm_info(const cora_ctx* ctx, int* rank, int* world);   /* rank -1 / world 0: no communicator */
 int cora_step_dist(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h, float eta_w,
                    int exact_clip, cora_step_out* out);
+/* MODE 1 (iPC, cora_step_ipc above; /root/reference/src/decoder_transformer.py:418-439) on a sharded batch: every one of
+ * the T iterations sums the per-vode sums of squares over the ranks between the two halves of its vode step
+ * (exact_clip != 0) and the flat dE/dW buffer before its clip + AdamW step (scale 1 / (B * world)), so every rank takes
+ * the weight steps of the global batch.  T + T small collectives per batch, eager launches (as cora_step_ipc). */
+int cora_step_ipc_dist(cora_ctx* ctx, const float* x, int x_on_device, int T, const float* eta_h,
+                       const float* eta_w, int exact_clip, cora_step_out* out);
 /* Graph vs eager collectives, agreed across ranks before the first replay (no counterpart in the reference,
  * which is single-device; its jit compiles one executable per (config, T, B), src/decoder_transformer.py:392).
  * After the first cora_step_dist (which always runs eagerly), cora_dist_prepare CAPTURES -- does not launch --

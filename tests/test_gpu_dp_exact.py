@@ -196,3 +196,48 @@ def test_in_library_rccl_world1_matches_single_gpu_step(name, exact):
         assert np.abs(x - y).max() <= 2e-5 * np.abs(x).max()
     for k in wa:
         assert np.abs(wa[k] - wb[k]).max() <= 1e-4 * max(np.abs(wa[k]).max(), 1e-3), k
+
+
+@pytest.mark.parametrize("name", ["fused_shape", "general_h2", "rows_n256_h2"])
+@pytest.mark.parametrize("exact", [True, False])
+def test_ipc_mode_in_library_rccl_world1_matches_single_gpu(name, exact):
+    """MODE 1 (`update_weights_every_inference_step`, /root/reference/src/decoder_transformer.py:418-439) on the
+    data-parallel entry point `cora_step_ipc_dist`: with a world-size-1 communicator the per-step all-reduces of the
+    sums-of-squares row and of dE/dW are identities, so two batches must reproduce `cora_step_ipc` -- vodes, energies,
+    the T AdamW steps per batch.  (More than one rank: same collectives as cora_step_dist, unverified on hardware.)"""
+    import ctypes as C
+    import cora_amd as ca
+    from cora_amd.dist import DataParallel
+    case, T = _case(name)
+    res = []
+    for dist_path in (False, True):
+        model, ow, oh = build_model(case, ipc=True)
+        if dist_path:
+            dp = DataParallel(model, case["x"].shape[0], backend="rccl", exact_clip=exact)
+            assert dp.in_library
+        outs = [ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh) for _ in range(2)]
+        tot, per = ca.step_energies(model, T)
+        res.append((outs, [model.vodes[l].h.get() for l in range(len(case["h"]))], model.get_weights(), tot,
+                    model.get_adam_state()[2]))
+        model.close()
+    (a, ha, wa, ea, ca_), (b, hb, wb, eb, cb_) = res
+    assert ca_ == cb_ == 2 * T
+    for oa, ob in zip(a, b):
+        assert oa[0] == pytest.approx(ob[0], rel=1e-6) and oa[1] == pytest.approx(ob[1], rel=1e-6) and oa[4] == pytest.approx(ob[4], rel=1e-6)
+    np.testing.assert_allclose(ea, eb, rtol=1e-6)
+    for x, y in zip(ha, hb):
+        assert np.abs(x - y).max() <= 2e-5 * np.abs(x).max()
+    for k in wa:
+        assert np.abs(wa[k] - wb[k]).max() <= 1e-4 * max(np.abs(wa[k]).max(), 1e-3), k
+
+
+def test_ipc_mode_needs_the_in_library_backend():
+    """The split (torch.distributed) transport has no per-inference-step weight exchange: it must say so."""
+    import cora_amd as ca
+    from cora_amd.dist import DataParallel
+    case, T = _case("general_h2")
+    model, ow, oh = build_model(case, ipc=True)
+    DataParallel(model, case["x"].shape[0], backend="torch")
+    with pytest.raises(NotImplementedError, match="backend='rccl'"):
+        ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh)
+    model.close()
