@@ -297,6 +297,8 @@ struct RowsP {
 };
 bool fused_rows_supported(long long rows, int D, int M);
 size_t fused_rows_colpart_floats(int L, long long rows);
+// store: 0 inference step, 1 learning-phase store pass, 2 one block of the status-"forward" walk (rows_qkv and rows_mid
+// only: L = 1, X = the block's input rows, E2 = where its output rows go, weight offsets advanced to the block)
 int launch_rows_qkv(const RowsP& p, int store, hipStream_t st);
 int launch_rows_mid(const RowsP& p, int store, hipStream_t st);
 int launch_rows_out(const RowsP& p, int store, hipStream_t st);

@@ -827,6 +827,29 @@ int chain_forward(cora_ctx* c, bool into_vodes, double* mse = nullptr) {
     out_proj(c, into_vodes ? vode_ptr(c, c->Hs, L + 1) : cur, c->z, OUT_STORE, nullptr, nullptr);
     return 0;
   }
+  static const bool no_rows_chain = getenv("CORA_NO_ROWS_CHAIN") != nullptr;   // diagnostic / cross-check: per-op walk on the row-tile path
+  if (c->frows && L > 0 && !no_rows_chain) {
+    // row-tile path: each block of the walk is rows_qkv -> attention -> rows_mid (chain mode) instead of seven per-op launches
+    const long long D = c->D, M = c->M;
+    for (int i = 0; i < L; ++i) {
+      float* nxt = into_vodes ? vode_ptr(c, c->Hs, i + 2) : (cur == c->ua ? c->ub : c->ua);
+      RowsP r; fill_rows(c, r, nullptr, nullptr);
+      r.L = 1; r.edge = 0; r.X = cur; r.E2 = nxt; r.delta = nullptr; r.dqa = nullptr;
+      r.oLn1g += i * D; r.oLn1b += i * D; r.oLn2g += i * D; r.oLn2b += i * D;
+      r.oWqkv += i * 3 * D * D; r.oWo += i * D * D; r.oW1 += i * M * D; r.ob1 += i * M; r.oW2 += i * D * M; r.ob2 += i * D;
+      { KScope s(c, K_ROWS, 2.0 * c->BN * D * 3 * D, 4.0 * c->BN * 4 * D);
+        if (launch_rows_qkv(r, 2, c->st)) FAIL(-3, "rows_qkv (chain): launch set-up failed"); }
+      { KScope s(c, K_ATTN_FWD, 4.0 * c->B * (double)c->N * c->N * D, 4.0 * c->BN * 4 * D);
+        if (c->cfg.dtype_mode == 1 && attn_fwd_bf16_supported(c->N, c->H, c->D)) {
+          if (launch_attn_fwd_bf16(c->qkv, c->att, c->lse, c->B, c->N, c->H, c->D, c->st)) FAIL(-3, "attention (bf16): launch set-up failed");
+        } else if (launch_attn_fwd(c->qkv, c->att, c->lse, c->B, c->N, c->H, c->D, c->st)) FAIL(-3, "attention: head dim not supported"); }
+      { KScope s(c, K_ROWS, c->BN * (2.0 * D * D + 4.0 * D * M), 4.0 * c->BN * 3 * D);
+        if (launch_rows_mid(r, 2, c->st)) FAIL(-3, "rows_mid (chain): launch set-up failed"); }
+      cur = nxt;
+    }
+    out_proj(c, cur, c->z, OUT_STORE, nullptr, nullptr);
+    return 0;
+  }
   for (int i = 0; i < L; ++i) {
     float* nxt = into_vodes ? vode_ptr(c, c->Hs, i + 2) : (cur == c->ua ? c->ub : c->ua);
     int rc = block_forward(c, 1, i, hand_on(cur, i), nxt, OUT_STORE, nullptr, nullptr);

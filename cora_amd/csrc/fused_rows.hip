@@ -53,7 +53,9 @@ __device__ __forceinline__ void rows_coords(const RowsP& p, int& g, long long& t
   tile = j % ntile;
 }
 
-enum { RMODE_INFER = 0, RMODE_STORE = 1 };
+// RMODE_CHAIN: status "forward" walk (INIT pass, reconstruction): one block per launch, rows_qkv as it is, rows_mid stops
+// at u = x + y + MLP and writes it where the next block reads (p.E2), no backward
+enum { RMODE_INFER = 0, RMODE_STORE = 1, RMODE_CHAIN = 2 };
 
 // ---- edge layers as extra workgroups of the inference launches (P = 48 only, like fused_block.hip: edge_path) ----
 //   top    (rows_qkv launch): e_1 = h_1 - (h_0 Wp^T + bp + pos), energy of vode 1, g_0 = -s_0 e_1 Wp and its sum of squares
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void rows_mid_kernel(RowsP p) {
       ln_rowT(y, gm, bt, xh, zn);
       if (MODE == RMODE_STORE) store_rowT(zn, p.S_xn2 + srow_g * D, grp);
     }
-    load_rowT(hn, p.X + voff + nl, D, grp);     // the next vode's rows: the HBM latency runs under the MLP
+    if (MODE != RMODE_CHAIN) load_rowT(hn, p.X + voff + nl, D, grp);     // the next vode's rows: the HBM latency runs under the MLP
     f32x4 zacc[4];
     zero4(zacc);
 #pragma unroll
@@ -283,6 +285,9 @@ __global__ __launch_bounds__(256, 2) void rows_mid_kernel(RowsP p) {
           am[k] = g2.x; am[k + 1] = g2.y;
           a_keep[16 * mt + k] = gp2.x; a_keep[16 * mt + k + 1] = gp2.y;
         }
+      } else if (MODE == RMODE_CHAIN) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) am[k] = cora_gelu(am[k]);
       } else {
         float gpv[16];
 #pragma unroll
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void rows_mid_kernel(RowsP p) {
       }
       PUBLISH(1, t);                                        // W2[:, mt]
       if (mt < 3) PREFETCH(W1 + (mt + 1) * 64 * D, D);
-      else PREFETCH(W2T, D);                                // -> W2^T[0]
+      else if (MODE != RMODE_CHAIN) PREFETCH(W2T, D);       // -> W2^T[0]
       gemm_tile(t, am, zacc, i, grp);
     }
     float z[16], b2[16];
@@ -305,6 +310,10 @@ __global__ __launch_bounds__(256, 2) void rows_mid_kernel(RowsP p) {
     load_rowT(b2, pb + PB_B2, D, grp);
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = x[k] + y[k] + z[k] + b2[k];     // x now holds u
+  }
+  if (MODE == RMODE_CHAIN) {   // the next block's input rows
+    store_rowT(x, p.E2 + voff, grp);
+    return;
   }
   float r[16];
 #pragma unroll
@@ -516,6 +525,7 @@ static int rows_attrs() {
   const int sm = (int)rows_lds_mid();
   if (hipFuncSetAttribute((const void*)rows_mid_kernel<RMODE_INFER>, hipFuncAttributeMaxDynamicSharedMemorySize, sm) != hipSuccess) return -1;
   if (hipFuncSetAttribute((const void*)rows_mid_kernel<RMODE_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, sm) != hipSuccess) return -1;
+  if (hipFuncSetAttribute((const void*)rows_mid_kernel<RMODE_CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, sm) != hipSuccess) return -1;
   return 0;
 }
 
@@ -524,14 +534,16 @@ static bool rows_ok(const RowsP& p) { return p.L > 0 && p.rows > 0 && p.rows % 6
 int launch_rows_qkv(const RowsP& p, int store, hipStream_t st) {
   if (!rows_ok(p)) return -1;
   const dim3 grid((unsigned)((p.L + ((p.edge && !store) ? 1 : 0)) * (p.rows / 64)));
-  if (store) hipLaunchKernelGGL(rows_qkv_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_small(), st, p);
+  if (store == RMODE_CHAIN) hipLaunchKernelGGL(rows_qkv_kernel<RMODE_CHAIN>, grid, dim3(256), rows_lds_small(), st, p);
+  else if (store) hipLaunchKernelGGL(rows_qkv_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_small(), st, p);
   else hipLaunchKernelGGL(rows_qkv_kernel<RMODE_INFER>, grid, dim3(256), rows_lds_small(), st, p);
   return 0;
 }
 int launch_rows_mid(const RowsP& p, int store, hipStream_t st) {
   if (!rows_ok(p) || rows_attrs()) return -1;
   const dim3 grid((unsigned)(p.L * (p.rows / 64)));
-  if (store) hipLaunchKernelGGL(rows_mid_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_mid(), st, p);
+  if (store == RMODE_CHAIN) hipLaunchKernelGGL(rows_mid_kernel<RMODE_CHAIN>, grid, dim3(256), rows_lds_mid(), st, p);
+  else if (store) hipLaunchKernelGGL(rows_mid_kernel<RMODE_STORE>, grid, dim3(256), rows_lds_mid(), st, p);
   else hipLaunchKernelGGL(rows_mid_kernel<RMODE_INFER>, grid, dim3(256), rows_lds_mid(), st, p);
   return 0;
 }

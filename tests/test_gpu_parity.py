@@ -588,6 +588,52 @@ def test_init_forward_energy_api(name, vode_ln):
     model.close()
 
 
+@pytest.mark.parametrize("per_op_walk", [False, True])
+@pytest.mark.parametrize("name", ["rows_n256_h2_L3", "rows_n64_P16_h4", "rows_n512_h1_B2", "cfg5_video_small"])
+def test_rows_path_init_and_reconstruction_walk(name, per_op_walk, monkeypatch):
+    """Row-tile path: the status-"forward" walk (INIT pass and reconstruction) runs rows_qkv -> attention -> rows_mid in
+    chain mode, one block per launch trio; CORA_NO_ROWS_CHAIN=1 keeps the seven per-op launches per block.  Both against
+    the oracle: INIT vodes, the reconstruction, and the two against each other through train_mse of a whole step."""
+    import cora_amd as ca
+    import torch
+    if per_op_walk:
+        monkeypatch.setenv("CORA_NO_ROWS_CHAIN", "1")
+    shape, p, D, H, L, B, T = CASES[name]
+    case = make_case(shape, p, D, H, L, B, seed=13)
+    model, ow, oh = build_model(case)
+    assert model.kernel_path() == "fused-rows"
+    model.init_vodes(B, h0=case["h0"])
+    href = R.init_vodes(case["h0"], case["W"], case["pos"], case["dims"])
+    for l in range(L + 2):
+        assert relerr(model.vodes[l].h.get(), href[l]) < TOL, l
+    for l, t in enumerate(case["h"]):
+        model.vodes[l].h.set(t)
+    with ca.step(model, ca.STATUS_FORWARD):
+        rec = ca.forward(None, model=model)
+    Wt = {k: torch.as_tensor(v, dtype=torch.float64) for k, v in case["W"].items()}
+    ht = [torch.as_tensor(t, dtype=torch.float64) for t in case["h"]]
+    rec_ref = R.predictions(ht, Wt, torch.as_tensor(case["pos"], dtype=torch.float64), case["dims"], chain=True)[-1].numpy()
+    assert relerr(rec, rec_ref) < TOL
+    ref = R.train_on_batch(T, case["x"], case["W"], case["h"], case["pos"], case["dims"], case["hp"], [0.095] * T, 1e-3)
+    out = ca.train_on_batch(T, case["x"], model=model, optim_w=ow, optim_h=oh)
+    assert out[4] == pytest.approx(ref["train_mse"], rel=TOL)
+    model.close()
+
+
+def test_rows_path_walk_in_bf16_mode():
+    """bf16 mode on the row-tile path: the walk uses the bf16-MFMA attention between the fp32 row kernels (bar 1e-2)."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = CASES["rows_n256_h2_L3"]
+    case = make_case(shape, p, D, H, L, B, seed=13)
+    model, ow, oh = build_model(case, compute_dtype="bf16")
+    assert model.kernel_path() == "fused-rows"
+    model.init_vodes(B, h0=case["h0"])
+    href = R.init_vodes(case["h0"], case["W"], case["pos"], case["dims"])
+    for l in range(L + 2):
+        assert relerr(model.vodes[l].h.get(), href[l]) < 1e-2, l
+    model.close()
+
+
 @pytest.mark.parametrize("name", ["g_0block", "g_1block", "g_2block_h2_reg_clip", "g_video"])
 def test_golden_vectors(name):
     """HIP path against the committed fixtures (tests/golden/*.npz, made by make_golden.py)."""
