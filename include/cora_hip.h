@@ -269,8 +269,12 @@ int cora_energy(cora_ctx* ctx, const float* x_host, double* E, double* per_layer
                 float* xhat_host, size_t n_floats);
 
 /* --- measurement ---------------------------------------------------------------------------- */
-/* Runs one inference step eagerly with HIP events around every launch and reports, per kernel
- * kind, launches / total ms / algorithmic FLOPs and bytes.  names: array of `cap` char[32]. */
+/* Runs inference steps eagerly (step size 0; vodes and momentum are restored afterwards) with HIP events on the ctx
+ * stream and reports, per kernel kind, launches / total ms / algorithmic FLOPs and bytes over 5 steps.  Before it
+ * records it keeps the GPU under load for >= 60 ms (clocks take tens of milliseconds to come back after an idle
+ * period), and the fused block kernel is timed as a burst of 8 identical back-to-back launches under one event
+ * pair, counted as one launch of the average duration -- what a graph replay executes.  names: `cap` x char[32].
+ * No counterpart in the reference (bench.py's roofline leg). */
 int cora_profile_step(cora_ctx* ctx, int cap, char* names, int* launches, double* ms,
                       double* flops, double* bytes, int* n_out);
 int cora_sync(cora_ctx* ctx);
