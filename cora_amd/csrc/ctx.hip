@@ -915,7 +915,6 @@ static const char* check_config(const cora_config* cfg) {
   if (cfg->N < 1 || cfg->P < 4 || cfg->D < 4 || cfg->H < 1 || cfg->L < 0 || cfg->B < 1 || cfg->M < 4) return "non-positive dimension";
   if (cfg->D % cfg->H) return "hidden_size must be divisible by num_heads";
   if (cfg->D % 4 || cfg->P % 4 || cfg->M % 4) return "D, P and M must be multiples of 4 (16-byte rows)";
-  if (((long long)cfg->B * cfg->N) % 4) return "B*N must be a multiple of 4";
   if (cfg->L + 3 > 64) return "too many blocks (L <= 61)";
   {   // the GEMM epilogue addresses one group's output with 32-bit element offsets
     long long widest = cfg->M > 3 * cfg->D ? cfg->M : 3 * cfg->D;

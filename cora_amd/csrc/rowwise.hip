@@ -141,13 +141,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
     }
   }
   if (p.mode == 1 && p.red) {
-    // rows of one block may straddle two groups only if rows_per_group % 16 != 0: reduce per wave then
-    // (each wave = 4 rows) -- the launcher guarantees rows_per_group % 4 == 0.
-    // each wave = 4 rows of one group (rows_per_group % 4 == 0); 8 slots per layer spread the
-    // same-address atomic traffic (one word takes ~88 atomics/us)
-    double tot = wave_sum_d(red);
-    if ((threadIdx.x & 63) == 0 && live)
-      atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 7)], tot);
+    // a wave holds 4 consecutive rows; 8 slots per layer spread the same-address atomic traffic (one word takes
+    // ~88 atomics/us).  The 4 rows share a group (= vode) unless rows_per_group % 4 != 0 puts a group boundary inside
+    // the wave: then each row's 16 lanes reduce and add on their own (wave-uniform choice).
+    const long long wr0 = (long long)blockIdx.x * 16 + ((threadIdx.x >> 6) << 2);
+    const long long wr3 = (wr0 + 3 < rows) ? wr0 + 3 : rows - 1;
+    const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 7;
+    if (wr0 >= rows || wr0 / p.rows_per_group == wr3 / p.rows_per_group) {
+      double tot = wave_sum_d(red);
+      if ((threadIdx.x & 63) == 0 && live) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + slot], tot);
+    } else {
+      double tot = red;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      if (sub == 0 && live) atomicAdd(&p.red[((long long)g * p.red_stride) * 8 + slot], tot);
+    }
     (void)red_sh;
   }
 }
@@ -166,7 +174,6 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long lo
 
 int launch_ln_bwd(const LnBwdP& p, hipStream_t st) {
   long long rows = (long long)p.rows_per_group * p.groups;
-  if (p.rows_per_group % 4 != 0) return -2;
   dim3 grid((unsigned)((rows + 15) / 16));
   int nv = (p.D + 63) / 64;
 #define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<NVV>), grid, dim3(256), 0, st, p)

@@ -49,6 +49,10 @@ CASES = {
     "d128_h4_P16": ((1, 32, 32), 4, 128, 4, 2, 2, 3),
     "d96_h2_P192": ((3, 64, 64), 8, 96, 2, 2, 2, 3),
     "n36_h2_ragged_chunk": ((3, 24, 24), 4, 32, 2, 2, 2, 3),   # N = 36: masked rows in the single-chunk attention kernels
+    # odd row counts (B * N = 147 / 243): a LayerNorm-backward wave's four rows straddle two vodes, attention tiles
+    # with one live row (49 = 3 x 16 + 1; 81 = 64 + 16 + 1)
+    "n49_h2_odd_rows": ((1, 28, 28), 4, 64, 2, 2, 3, 3),
+    "n81_h3_odd_rows": ((3, 36, 36), 4, 96, 3, 3, 3, 2),
     "d96_h2": ((3, 32, 32), 4, 96, 2, 2, 2, 3),               # wide2: heads of 48 as three 16-column slices
     "d96_h1_shallow": ((3, 32, 32), 4, 96, 1, 2, 3, 3),        # wide2: one head of 96 as three 32-column slices
     "d96_h2_12block": ((3, 32, 32), 4, 96, 2, 12, 2, 3),
