@@ -510,6 +510,7 @@ def train_on_batch_ipc(T: int, x: np.ndarray, weights: Dict[str, np.ndarray], h:
     keys = list(W.keys())
     energies, w_energies = [], []
     grads = w_grad = None
+    w_grad_minabs = None          # per entry, the smallest |dE/dW| over the T steps (the parity test's noise filter)
     for t in range(T):
         E, _, grads, _ = h_gradients(hs, W, pos_t, y, dims, hp)
         energies.append(float(E))
@@ -522,6 +523,8 @@ def train_on_batch_ipc(T: int, x: np.ndarray, weights: Dict[str, np.ndarray], h:
         w_energies.append(float(Ew.detach()))
         wg = torch.autograd.grad(Ew, [Wg[k] for k in keys])
         w_grad = {k: g.detach() for k, g in zip(keys, wg)}
+        w_grad_minabs = ({k: v.abs() for k, v in w_grad.items()} if w_grad_minabs is None else
+                         {k: torch.minimum(w_grad_minabs[k], v.abs()) for k, v in w_grad.items()})
         g_list = _clip([w_grad[k] * (1.0 / B) for k in keys], hp.clip_w)
         adam.count += 1
         newW = {}
@@ -539,5 +542,6 @@ def train_on_batch_ipc(T: int, x: np.ndarray, weights: Dict[str, np.ndarray], h:
         mse = ((xhat.clamp(0.0, 1.0) - y.clamp(0.0, 1.0)) ** 2).mean()
     return {"energies": np.array(energies), "w_energies": np.array(w_energies),
             "final_h_grad": [g.detach().numpy() for g in grads], "w_grad": {k: v.numpy() for k, v in w_grad.items()},
+            "w_grad_minabs": {k: v.numpy() for k, v in w_grad_minabs.items()},
             "h": [t.detach().numpy() for t in hs], "weights": {k: v.detach().numpy() for k, v in W.items()},
             "train_mse": float(mse), "adam": adam}

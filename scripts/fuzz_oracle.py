@@ -5,7 +5,10 @@ normalisation, in the fp32, bf16x3 (bars of tests/test_gpu_parity.py::run_case: 
 bf16 (1e-2) modes.  Whatever kernel path the library picks for the shape is the one checked; the line names it.
 Run on the GPU box:  python scripts/fuzz_oracle.py [n_cases] [seed] [odd].  One line per case; exits non-zero on a miss.
 "odd": only shapes whose row count B * N is odd (49 or 81 tokens, odd batch) with at least one block -- LayerNorm backward
-waves that straddle two vodes, attention tiles with a single live row."""
+waves that straddle two vodes, attention tiles with a single live row.  "loops": the other loops of the path on random
+shapes in fp32 -- iPC mode (weights updated after every vode step), the vode-state LayerNorm option, and
+unmask_on_batch_enhanced (random mask kind, clamp strength, with / without the vode-state LayerNorm) -- through the checks
+of tests/test_gpu_parity.py and tests/test_gpu_unmask.py."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -20,6 +23,9 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     odd = len(sys.argv) > 3 and sys.argv[3] == "odd"
+    loops = len(sys.argv) > 3 and sys.argv[3] == "loops"
+    if loops:
+        import tests.test_gpu_unmask as tu
     bad = 0
     for i in range(n):
         img, patch = IMAGES[int(rng.integers(0, len(IMAGES)))]
@@ -37,8 +43,26 @@ if __name__ == "__main__":
         name = f"fuzz{i}"
         tp.CASES[name] = (img, patch, H * hd, H, L, B, T)
         desc = dict(img=img, patch=patch, D=H * hd, H=H, L=L, B=B, T=T, mode=mode, gn=gn, **kw)
+        if loops:
+            kind = str(rng.choice(["ipc", "vln", "unmask", "unmask", "unmask_vln"]))
+            L, T, mode = max(L, 1), max(T, 2), kind
+            if kind.startswith("unmask") and len(img) == 4:     # the unmasking loop is for single images, here as in the reference (:862-894)
+                img, patch = (3, 32, 48), 4
+            tp.CASES[name] = (img, patch, H * hd, H, L, B, T)
+            desc = dict(img=img, patch=patch, D=H * hd, H=H, L=L, B=B, T=T, loop=kind)
         try:
-            if mode == "bf16":
+            if loops:
+                if kind == "ipc":
+                    tp.test_ipc_mode_weight_update_every_step(name)
+                elif kind == "vln":
+                    tp.run_case(name, vode_ln=True, l1=1e-3, l2=1e-3, clip_h=5.0)
+                else:
+                    tu.SHAPES[name] = tp.CASES[name]
+                    lower, alpha, ch = bool(rng.integers(0, 2)), float(rng.choice([1.0, 0.6])), float(rng.choice([2000.0, 3.0]))
+                    desc.update(lower_half=lower, alpha=alpha, clip_h=ch)
+                    tu._unmask_with_corruption(name, lower, alpha, ch, kind == "unmask_vln")
+                ok, msg = True, "within the test's bars"
+            elif mode == "bf16":
                 errs = tp.run_bf16_case(name)
                 worst = max(errs, key=errs.get)
                 ok, msg = errs[worst] <= tp.BF16_TOL, f"worst {worst} {errs[worst]:.2e}"

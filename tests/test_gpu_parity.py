@@ -450,7 +450,9 @@ def test_ipc_mode_weight_update_every_step(name):
     """MODE 1 of train_on_batch (`update_weights_every_inference_step`, reference :418-439) against the
     oracle: vodes and energies to the fp32 bar.  AdamW's first steps turn every gradient entry into
     roughly +-eta_w regardless of its size, so weights after T such steps are compared on the
-    entries whose fp64 gradient is not noise-sized (|g| > 1e-3 max|g|), and the LAST iteration's vode
+    entries whose fp64 gradient is not noise-sized at ANY of the T steps (|g_t| > 1e-3 max|g|: an entry that is
+    noise at step 1 alone already takes +-eta_w with the sign of its rounding error -- random shapes of
+    scripts/fuzz_oracle.py showed 0.03 ... 0.4 of the total step on such entries, the fp32 oracle itself 0.1), and the LAST iteration's vode
     gradient -- evaluated with weights that went through T-1 such steps -- is held to 1e-3."""
     import cora_amd as ca
     shape, p, D, H, L, B, T = CASES[name]
@@ -480,7 +482,7 @@ def test_ipc_mode_weight_update_every_step(name):
     neww = model.get_weights()
     gmax = max(np.abs(v).max() for v in ref["w_grad"].values())
     for k, v in ref["weights"].items():
-        sel = np.abs(ref["w_grad"][k]) > 1e-3 * gmax
+        sel = ref["w_grad_minabs"][k] > 1e-3 * gmax
         if sel.any():
             d = np.abs(neww[k].astype(np.float64) - v)[sel].max()
             d32 = np.abs(r32["weights"][k].astype(np.float64) - v)[sel].max()
