@@ -8,7 +8,8 @@ Run on the GPU box:  python scripts/fuzz_oracle.py [n_cases] [seed] [odd].  One 
 waves that straddle two vodes, attention tiles with a single live row.  "loops": the other loops of the path on random
 shapes in fp32 -- iPC mode (weights updated after every vode step), the vode-state LayerNorm option, and
 unmask_on_batch_enhanced (random mask kind, clamp strength, with / without the vode-state LayerNorm) -- through the checks
-of tests/test_gpu_parity.py and tests/test_gpu_unmask.py."""
+of tests/test_gpu_parity.py and tests/test_gpu_unmask.py.  "extremes": a fixed list at the edges of what the library
+accepts (D = 768, 12 heads, 1024 tokens off the D = 64 kernels, 20 blocks, a 16 x 16 patch), each in fp32 and bf16."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -18,6 +19,10 @@ IMAGES = [((3, 16, 16), 4), ((3, 24, 24), 4), ((1, 28, 28), 4), ((3, 32, 32), 4)
           ((3, 112, 112), 8), ((3, 96, 96), 8)]
 HEAD_DIMS = [16, 24, 32, 48, 64, 96, 128]
 
+EXTREMES = [((3, 112, 112), 8, 768, 6, 1, 2, 2), ((3, 32, 32), 4, 768, 12, 2, 2, 2), ((3, 64, 64), 4, 512, 4, 1, 1, 2),
+            ((3, 16, 16), 4, 32, 2, 20, 2, 2), ((3, 128, 128), 4, 96, 2, 1, 1, 2), ((3, 64, 64), 16, 64, 2, 2, 3, 2),
+            ((3, 128, 128), 4, 128, 1, 1, 1, 2), ((3, 224, 224), 16, 768, 12, 1, 1, 2)]
+
 if __name__ == "__main__":
     import tests.test_gpu_parity as tp
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -26,6 +31,9 @@ if __name__ == "__main__":
     loops = len(sys.argv) > 3 and sys.argv[3] == "loops"
     if loops:
         import tests.test_gpu_unmask as tu
+    extremes = len(sys.argv) > 3 and sys.argv[3] == "extremes"
+    if extremes:
+        n = 2 * len(EXTREMES)
     bad = 0
     for i in range(n):
         img, patch = IMAGES[int(rng.integers(0, len(IMAGES)))]
@@ -42,6 +50,10 @@ if __name__ == "__main__":
         gn = bool(rng.integers(0, 2))
         name = f"fuzz{i}"
         tp.CASES[name] = (img, patch, H * hd, H, L, B, T)
+        if extremes:
+            tp.CASES[name] = EXTREMES[i // 2]
+            img, patch, _, H, L, B, T = EXTREMES[i // 2]
+            hd, mode, gn, kw = EXTREMES[i // 2][2] // H, ("fp32", "bf16")[i % 2], False, dict(clip_h=3.0)
         desc = dict(img=img, patch=patch, D=H * hd, H=H, L=L, B=B, T=T, mode=mode, gn=gn, **kw)
         if loops:
             kind = str(rng.choice(["ipc", "vln", "unmask", "unmask", "unmask_vln"]))
