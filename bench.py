@@ -532,8 +532,6 @@ def main():
         B = args.global_batch // world
     else:
         B = args.batch or mc0.batch_size
-    if (B * 64) % 4:
-        raise SystemExit("per-GPU batch too ragged")
     ctx_args = (rank, local_rank, world, dist)
     headline = args.config == "6block" and not over
     extras_on = not args.no_extra and headline
@@ -549,7 +547,7 @@ def main():
             other_name, other_B = "weak", (args.batch or mc0.batch_size)
         else:
             gb = REFERENCE_BATCH if args.batch is None else args.batch
-            if gb % world == 0 and ((gb // world) * 64) % 4 == 0:
+            if gb % world == 0:
                 other_name, other_B = "strong", gb // world
     other_res = None
     if other_B:

@@ -76,9 +76,23 @@ class DataParallel:
         if self.in_library:
             lib = _lib.load()
             ident = [None]
+            # every rank asks for an id (rank 0's is the one used): that call needs librccl loaded, so a rank on
+            # which it cannot be bound finds out HERE, and the ranks agree over the torch group before any of them
+            # enters ncclCommInitRank -- where the others would wait for the missing rank until a timeout
+            raw = C.create_string_buffer(128)
+            rc = lib.cora_comm_unique_id(raw, 128)
+            ok = 1 if rc == 0 else 0
+            if world > 1:
+                on_gpu = dist.get_backend(group) != "gloo"
+                flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", model.device) if on_gpu else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                model._dp = None
+                if rc != 0:
+                    _lib.check(rc, None)
+                raise RuntimeError("in-library RCCL could not be bound on every rank")
             if rank == 0:
-                raw = C.create_string_buffer(128)
-                _lib.check(lib.cora_comm_unique_id(raw, 128), None)
                 ident[0] = raw.raw
             if world > 1:
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
