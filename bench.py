@@ -376,7 +376,8 @@ def measure(args, cfg_name, over, B, T, steps, warmup, rank, local_rank, world, 
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor(np.concatenate([[elapsed], per_call]), dtype=torch.float64, device="cuda")
+        t = torch.tensor(np.concatenate([[elapsed], per_call]), dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t = t.cpu().numpy()
         elapsed, per_call = float(t[0]), t[1:]
@@ -494,6 +495,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal of the N > 1 flow on a one-GPU box: every rank on device 0, gloo for the process group and the
+    # torch data-parallel backend (RCCL refuses two ranks on one device).  Exercises sharding, both scalings, the
+    # extras and the line; its throughput means nothing and the line says so.
+    one_gpu = os.environ.get("CORA_BENCH_ONE_GPU") == "1" and world > 1
+    if one_gpu:
+        local_rank = 0
+        args.dp_backend = "torch"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run_launch:
@@ -519,7 +527,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if force_dp and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         tick()
 
     over = {k: v for k, v in (("hidden_size", args.hidden_size), ("num_heads", args.num_heads),
@@ -634,6 +645,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(mc, tc, B, r["T"])
         else:
             result["cpu_baseline"] = None
+        if one_gpu:
+            result["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo (CORA_BENCH_ONE_GPU=1): flow check, not a throughput"
         if "CORA_HIP_LIB" in os.environ:    # not a product number: the library was swapped for a diagnostic build
             result["diagnostic_library"] = os.environ["CORA_HIP_LIB"]
         sys.stdout.flush()
