@@ -926,7 +926,7 @@ static const char* check_config(const cora_config* cfg) {
   if (cfg->L > 0) {
     int dh = cfg->D / cfg->H;
     if (!(dh == 16 || dh == 24 || dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128)) return "head dim must be one of 16,24,32,48,64,96,128";
-    if (cfg->D > 768) return "hidden_size > 768 not supported by the LayerNorm kernels";
+    if (cfg->D > 1024) return "hidden_size > 1024 not supported by the LayerNorm kernels";
   }
   return nullptr;
 }

@@ -167,7 +167,7 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long lo
   int nv = (D + 63) / 64;
 #define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<NVV>), grid, dim3(256), 0, st, x, gamma, beta, sParam, xn, stats, rows_per_group, rows, D)
   if (nv == 1) LNF(1); else if (nv == 2) LNF(2); else if (nv <= 4) LNF(4); else if (nv <= 6) LNF(6);
-  else if (nv <= 12) LNF(12); else return -1;
+  else if (nv <= 12) LNF(12); else if (nv <= 16) LNF(16); else return -1;
 #undef LNF
   return 0;
 }
@@ -178,7 +178,7 @@ int launch_ln_bwd(const LnBwdP& p, hipStream_t st) {
   int nv = (p.D + 63) / 64;
 #define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<NVV>), grid, dim3(256), 0, st, p)
   if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else if (nv <= 4) LNB(4); else if (nv <= 6) LNB(6);
-  else if (nv <= 12) LNB(12); else return -1;
+  else if (nv <= 12) LNB(12); else if (nv <= 16) LNB(16); else return -1;
 #undef LNB
   return 0;
 }

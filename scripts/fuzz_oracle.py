@@ -9,7 +9,7 @@ waves that straddle two vodes, attention tiles with a single live row.  "loops":
 shapes in fp32 -- iPC mode (weights updated after every vode step), the vode-state LayerNorm option, and
 unmask_on_batch_enhanced (random mask kind, clamp strength, with / without the vode-state LayerNorm) -- through the checks
 of tests/test_gpu_parity.py and tests/test_gpu_unmask.py.  "extremes": a fixed list at the edges of what the library
-accepts (D = 768, 12 heads, 1024 tokens off the D = 64 kernels, 20 blocks, a 16 x 16 patch), each in fp32 and bf16."""
+accepts (D = 768 and 1024, 12 / 16 heads, 1024 tokens off the D = 64 kernels, 20 blocks, a 16 x 16 patch), each in fp32 and bf16."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -21,7 +21,8 @@ HEAD_DIMS = [16, 24, 32, 48, 64, 96, 128]
 
 EXTREMES = [((3, 112, 112), 8, 768, 6, 1, 2, 2), ((3, 32, 32), 4, 768, 12, 2, 2, 2), ((3, 64, 64), 4, 512, 4, 1, 1, 2),
             ((3, 16, 16), 4, 32, 2, 20, 2, 2), ((3, 128, 128), 4, 96, 2, 1, 1, 2), ((3, 64, 64), 16, 64, 2, 2, 3, 2),
-            ((3, 128, 128), 4, 128, 1, 1, 1, 2), ((3, 224, 224), 16, 768, 12, 1, 1, 2)]
+            ((3, 128, 128), 4, 128, 1, 1, 1, 2), ((3, 224, 224), 16, 768, 12, 1, 1, 2),
+            ((3, 224, 224), 16, 1024, 16, 1, 1, 2), ((3, 64, 64), 8, 1024, 8, 2, 2, 2)]
 
 if __name__ == "__main__":
     import tests.test_gpu_parity as tp

@@ -59,6 +59,7 @@ CASES = {
     "d96_h4_headdim24": ((3, 32, 32), 4, 96, 4, 2, 2, 3),      # wide2: heads of 24 = one and a half column groups, lane-masked slices
     "d96_h4_12block": ((3, 32, 32), 4, 96, 4, 12, 3, 3),
     "cfg4_shape_B1": ((3, 224, 224), 16, 384, 8, 2, 4, 2),
+    "d1024_h16_widest": ((3, 64, 64), 8, 1024, 16, 1, 2, 2),   # the widest hidden size the LayerNorm kernels take (16 float4 per lane)
     "cfg5_video_small": ((4, 3, 32, 32), 4, 64, 1, 2, 1, 2),
     # the row-tile fused kernels (fused_rows.hip: D = 64, B*N a multiple of 64, any sequence length) around attn.hip
     "rows_n256_h2_L3": ((4, 3, 32, 32), 4, 64, 2, 3, 1, 3),
