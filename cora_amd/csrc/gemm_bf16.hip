@@ -49,12 +49,20 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef BF_TK
 #define BF_TK 32
 #endif
-constexpr int TM = 128, TN = 128, TK = BF_TK;
+#ifndef BF_TM
+#define BF_TM 128
+#endif
+#ifndef BF_TN
+#define BF_TN 128
+#endif
+constexpr int TM = BF_TM, TN = BF_TN, TK = BF_TK;
 #ifndef BF_THREADS
 #define BF_THREADS 256
 #endif
 constexpr int NTHR = BF_THREADS, NWC = NTHR / 128;      // waves across the 128 columns (2 or 4); 2 wave rows of 64
 constexpr int WN = TN / NWC / 32;                        // 32-column MFMA tiles per wave (2 or 1)
+constexpr int WM = TM / 2 / 32;                          // 32-row MFMA tiles per wave (2 wave rows)
+constexpr int NVB = TN * TK / 4 / NTHR, NPB = TN * TK / 8 / NTHR;
 constexpr int KQ = TK / 4, NV = TM * TK / 4 / NTHR, RSTEP = NTHR / KQ;   // staging: float4 per row, per thread and operand, row step
 constexpr int LDR = TK + 8;          // bf16 per LDS row
 
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
 
   // staging: float4 #f of a 128 x TK tile = row f / KQ, k quad f % KQ; thread t takes #t + 256 i (row t / KQ + RSTEP i)
   const int srow = tid / KQ, skq = tid % KQ;
-  float4 ra[NV], rb[BPRE ? 1 : NV];
-  uint4 pbh[2], pbl[2], pb3[2];
+  float4 ra[NV], rb[BPRE ? 1 : NVB];
+  uint4 pbh[NPB], pbl[NPB], pb3[NPB];
   auto load_tiles = [&](int k0) {
     const int gk = k0 + 4 * skq;
     const bool kok = gk < p.K;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       // they are -- piece #f of the 128 x 32 tile = row f / 4, k octet f % 4; thread t takes #t and #t + 256
       static_assert(!BPRE || (NTHR == 256 && TK == 32), "pre-converted B staging is written for 256 threads, 32-deep slabs");
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NPB; ++i) {
         const int f = tid + 256 * i;
         const int gc = col0 + (f >> 2), gkb = k0 + 8 * (f & 3);
         const bool ok = gkb < p.K && gc < p.O;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
+      for (int i = 0; i < NVB; ++i) {
         const int gc = col0 + srow + RSTEP * i;
         rb[i] = (kok && gc < p.O) ? *reinterpret_cast<const float4*>(Bw + (long long)gc * p.ldb + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
     }
     if (BPRE) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NPB; ++i) {
         const int f = tid + 256 * i;
         const int o = (f >> 2) * LDR + 8 * (f & 3);
         *reinterpret_cast<uint4*>(&Bh[o]) = pbh[i];
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
+      for (int i = 0; i < NVB; ++i) {
         const float4 v = rb[i];
         const int o = (srow + RSTEP * i) * LDR + 4 * skq;
         const bf16x4 h = to_bf16(v);
@@ -181,16 +189,16 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
     }
   };
 
-  f32x16 acc[2][WN];
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
   // lane (r, hi) holds k = 16 kk + 8 hi .. + 7 of its row (A) / column (B): 16 bytes, one ds_read_b128
-  const int aoff = (64 * wr + r) * LDR + 8 * hi;
+  const int aoff = (32 * WM * wr + r) * LDR + 8 * hi;
   const int boff = (32 * WN * wc + r) * LDR + 8 * hi;
 
   load_tiles(0);
@@ -201,23 +209,23 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
     if (k0 + TK < p.K) load_tiles(k0 + TK);     // next tile into registers under the MFMAs
 #pragma unroll
     for (int kk = 0; kk < TK / 16; ++kk) {
-      bf16x8 ah[2], bh[WN], al[2], bl[WN];
+      bf16x8 ah[WM], bh[WN], al[WM], bl[WN];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) ah[m] = *reinterpret_cast<const bf16x8*>(&Ah[aoff + 32 * m * LDR + 16 * kk]);
+      for (int m = 0; m < WM; ++m) ah[m] = *reinterpret_cast<const bf16x8*>(&Ah[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
       for (int n = 0; n < WN; ++n) bh[n] = *reinterpret_cast<const bf16x8*>(&Bh[boff + 32 * n * LDR + 16 * kk]);
       if (SPLIT == 2) {   // smallest terms first: hi * lo, lo * hi, mid * mid
-        bf16x8 a3[2], b3[WN];
+        bf16x8 a3[WM], b3[WN];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) a3[m] = *reinterpret_cast<const bf16x8*>(&A3[aoff + 32 * m * LDR + 16 * kk]);
+        for (int m = 0; m < WM; ++m) a3[m] = *reinterpret_cast<const bf16x8*>(&A3[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
         for (int n = 0; n < WN; ++n) b3[n] = *reinterpret_cast<const bf16x8*>(&B3[boff + 32 * n * LDR + 16 * kk]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
+        for (int m = 0; m < WM; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
         for (int n = 0; n < WN; ++n) bl[n] = *reinterpret_cast<const bf16x8*>(&Bl[boff + 32 * n * LDR + 16 * kk]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < WM; ++m)
 #pragma unroll
           for (int n = 0; n < WN; ++n) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[m], bh[n], acc[m][n], 0, 0, 0);
@@ -228,11 +236,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
           }
       } else if (SPLIT) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
+        for (int m = 0; m < WM; ++m) al[m] = *reinterpret_cast<const bf16x8*>(&Al[aoff + 32 * m * LDR + 16 * kk]);
 #pragma unroll
         for (int n = 0; n < WN; ++n) bl[n] = *reinterpret_cast<const bf16x8*>(&Bl[boff + 32 * n * LDR + 16 * kk]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < WM; ++m)
 #pragma unroll
           for (int n = 0; n < WN; ++n) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);   // small terms first
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
           }
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
@@ -250,10 +258,10 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
   const GemmEp q = gemm_ep_ptrs(p, g);
   double red = 0.0;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n)
-      gemm_ep_tile<EP_STREAM>(p, q, acc[m][n], row0 + 64 * wr + 32 * m + 4 * hi, col0 + 32 * WN * wc + 32 * n + r, red);
+      gemm_ep_tile<EP_STREAM>(p, q, acc[m][n], row0 + 32 * WM * wr + 32 * m + 4 * hi, col0 + 32 * WN * wc + 32 * n + r, red);
   if (p.red) {      // energy / sum of squares of the whole workgroup (OUT_GRAD: 8 slots per vode, folded on the host)
     double* red_sh = reinterpret_cast<double*>(Ah);      // the tiles are dead: their memory carries the wave sums
     const double wsum = wave_sum_d(red);
