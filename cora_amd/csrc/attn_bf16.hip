@@ -20,6 +20,13 @@
 #include "attn_map.h"
 
 namespace {
+// four consecutive values as bf16 (8 bytes): the backward-data scratch kept as bf16 for the GEMM that reads it next
+__device__ __forceinline__ void store_bf16x4(__bf16* dst, const float4 v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 b; b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+  *reinterpret_cast<bf4*>(dst) = b;
+}
+
 
 #define CHB 64  // streamed rows per chunk
 
@@ -202,7 +209,7 @@ template <int DH> struct SmemQ {
 template <int DH, int NW, int OT>
 __global__ __launch_bounds__(64 * NW, (DH <= 64 && OT == 1) ? 4 : 1) void attn_bwd_q_bf16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ O, const float* __restrict__ lse2, const float* __restrict__ dO,
-    float* __restrict__ delta, float* __restrict__ dqkv, int nimg, int N, int H, int D) {
+    float* __restrict__ delta, float* __restrict__ dqkv, int nimg, int N, int H, int D, int out16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SmemQ<DH>& sm = *reinterpret_cast<SmemQ<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
@@ -276,11 +283,14 @@ __global__ __launch_bounds__(64 * NW, (DH <= 64 && OT == 1) ? 4 : 1) void attn_b
   for (int o = 0; o < OT; ++o) {
     const int qrow = rb * ROWS + 16 * (w + NW * o) + c;
     if (qrow < N) {
-      float* drow = dqkv + ((long long)img * N + qrow) * ld + h * DH;
+      const long long doff = ((long long)img * N + qrow) * ld + h * DH;
+      float* drow = dqkv + doff;
 #pragma unroll
-      for (int ct = 0; ct < DH / 16; ++ct)
-        *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) =
-            make_float4(acc[o][ct][0] * scale, acc[o][ct][1] * scale, acc[o][ct][2] * scale, acc[o][ct][3] * scale);
+      for (int ct = 0; ct < DH / 16; ++ct) {
+        const float4 v = make_float4(acc[o][ct][0] * scale, acc[o][ct][1] * scale, acc[o][ct][2] * scale, acc[o][ct][3] * scale);
+        if (out16) store_bf16x4(reinterpret_cast<__bf16*>(dqkv) + doff + 16 * ct + 4 * grp, v);
+        else *reinterpret_cast<float4*>(drow + 16 * ct + 4 * grp) = v;
+      }
     }
   }
 }
@@ -294,7 +304,7 @@ template <int DH> struct SmemKV {
 template <int DH, int NW, int OT>
 __global__ __launch_bounds__(64 * NW, OT == 1 ? (DH <= 48 ? 4 : DH <= 64 ? 3 : 1) : 1) void attn_bwd_kv_bf16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ lse2, const float* __restrict__ dO, const float* __restrict__ delta,
-    float* __restrict__ dqkv, int nimg, int N, int H, int D) {
+    float* __restrict__ dqkv, int nimg, int N, int H, int D, int out16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SmemKV<DH>& sm = *reinterpret_cast<SmemKV<DH>*>(smem_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, grp = lane >> 4;
@@ -381,13 +391,19 @@ __global__ __launch_bounds__(64 * NW, OT == 1 ? (DH <= 48 ? 4 : DH <= 64 ? 3 : 1
   for (int o = 0; o < OT; ++o) {
     const int krow = rb * ROWS + 16 * (w + NW * o) + c;
     if (krow < N) {
-      float* drow = dqkv + ((long long)img * N + krow) * ld + h * DH;
+      const long long doff = ((long long)img * N + krow) * ld + h * DH;
+      float* drow = dqkv + doff;
 #pragma unroll
       for (int ct = 0; ct < DH / 16; ++ct) {
-        *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) =
-            make_float4(dk[o][ct][0] * scale, dk[o][ct][1] * scale, dk[o][ct][2] * scale, dk[o][ct][3] * scale);
-        *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) =
-            make_float4(dv[o][ct][0], dv[o][ct][1], dv[o][ct][2], dv[o][ct][3]);
+        const float4 vk = make_float4(dk[o][ct][0] * scale, dk[o][ct][1] * scale, dk[o][ct][2] * scale, dk[o][ct][3] * scale);
+        const float4 vv = make_float4(dv[o][ct][0], dv[o][ct][1], dv[o][ct][2], dv[o][ct][3]);
+        if (out16) {
+          store_bf16x4(reinterpret_cast<__bf16*>(dqkv) + doff + D + 16 * ct + 4 * grp, vk);
+          store_bf16x4(reinterpret_cast<__bf16*>(dqkv) + doff + 2 * D + 16 * ct + 4 * grp, vv);
+        } else {
+          *reinterpret_cast<float4*>(drow + D + 16 * ct + 4 * grp) = vk;
+          *reinterpret_cast<float4*>(drow + 2 * D + 16 * ct + 4 * grp) = vv;
+        }
       }
     }
   }
@@ -528,7 +544,7 @@ int run_fwd_bf16_dh(const float* qkv, float* O, float* lse2, int nimg, int N, in
 
 template <int DH, int NW, int OT>
 int run_bwd_bf16(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
-                 float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+                 float* dqkv, int nimg, int N, int H, int D, hipStream_t st, int out16) {
   const size_t smq = sizeof(SmemQ<DH>), smkv = sizeof(SmemKV<DH>);
   static bool attr_set[64] = {};
   if (smkv > 48 * 1024 && first_use_on_device(attr_set)) {
@@ -537,8 +553,8 @@ int run_bwd_bf16(const float* qkv, const float* O, const float* lse2, const floa
   }
   constexpr int ROWS = 16 * NW * OT;
   const dim3 grid(attn_grid((N + ROWS - 1) / ROWS, H, nimg));
-  hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<DH, NW, OT>), grid, dim3(64 * NW), smq, st, qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D);
-  hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<DH, NW, OT>), grid, dim3(64 * NW), smkv, st, qkv, lse2, dO, delta, dqkv, nimg, N, H, D);
+  hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<DH, NW, OT>), grid, dim3(64 * NW), smq, st, qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, out16);
+  hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<DH, NW, OT>), grid, dim3(64 * NW), smkv, st, qkv, lse2, dO, delta, dqkv, nimg, N, H, D, out16);
   return 0;
 }
 
@@ -547,14 +563,14 @@ int run_bwd_bf16(const float* qkv, const float* O, const float* lse2, const floa
 // 128 rows 355 / 202 us, 256 rows (8 waves x 2 own tiles, CORA_ATTN_BF16_ROWS=256 only) 390 / 225 us.
 template <int DH>
 int run_bwd_bf16_dh(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
-                    float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+                    float* dqkv, int nimg, int N, int H, int D, hipStream_t st, int out16) {
   int rows = ((long long)((N + 127) / 128) * H * nimg >= 512) ? 128 : 64;
   if (const char* e = getenv("CORA_ATTN_BF16_ROWS")) { const int v = atoi(e); if (v == 64 || v == 128 || (v == 256 && DH <= 64)) rows = v; }
   if constexpr (DH <= 64) {
-    if (rows == 256) return run_bwd_bf16<DH, 8, 2>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st);
+    if (rows == 256) return run_bwd_bf16<DH, 8, 2>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st, out16);
   }
-  if (rows == 128) return run_bwd_bf16<DH, 8, 1>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st);
-  return run_bwd_bf16<DH, 4, 1>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st);
+  if (rows == 128) return run_bwd_bf16<DH, 8, 1>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st, out16);
+  return run_bwd_bf16<DH, 4, 1>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st, out16);
 }
 
 }  // namespace
@@ -568,9 +584,9 @@ bool attn_bwd_bf16_supported(int N, int H, int D) {
 }
 
 int launch_attn_bwd_bf16(const float* qkv, const float* O, const float* lse2, const float* dO, float* delta,
-                         float* dqkv, int nimg, int N, int H, int D, hipStream_t st) {
+                         float* dqkv, int nimg, int N, int H, int D, hipStream_t st, int out16) {
   if (!attn_bwd_bf16_supported(N, H, D)) return -1;
-#define CALL(X) run_bwd_bf16_dh<X>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st)
+#define CALL(X) run_bwd_bf16_dh<X>(qkv, O, lse2, dO, delta, dqkv, nimg, N, H, D, st, out16)
   switch (D / H) {
     case 16: return CALL(16);
     case 32: return CALL(32);

@@ -124,6 +124,10 @@ struct GemmP {
   // term (three-term form) -- indexed like Bw (ctx.hip keeps the copies fresh); null -> B is converted from
   // Bw while staging
   const unsigned short* Bh; const unsigned short* Bl; const unsigned short* B3;
+  // bf16 mode, backward-data scratch kept as bf16 (ctx.hip: block_backward): a16 -- A points at bf16 elements (same lda / sA,
+  // in elements; plain form with pre-converted B only: the kernel would round A to bf16 anyway, so the products are
+  // bit-identical); c16 -- OUT_GELUGRAD stores C as bf16 (the next GEMM's a16 operand)
+  int a16, c16;
 };
 
 void launch_gemm(const GemmP& p, bool a_kouter, bool b_kouter, hipStream_t st);
@@ -154,7 +158,8 @@ bool attn_bwd_bf16_supported(int N, int H, int D);
 bool attn_fwd_bf16_supported(int N, int H, int D);
 int launch_attn_fwd_bf16(const float* qkv, float* O, float* lse2, int nimg, int N, int H, int D, hipStream_t st);
 int launch_attn_bwd_bf16(const float* qkv, const float* O, const float* lse2, const float* dO,
-                         float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st);
+                         float* delta, float* dqkv, int nimg, int N, int H, int D, hipStream_t st,
+                         int out16 = 0 /* dqkv written as bf16 (same element offsets): the next GEMM's GemmP::a16 operand */);
 
 // ---- row-wise / element-wise ---------------------------------------------------------------------
 int launch_ln_fwd(const float* x, const float* gamma, const float* beta, long long sParam,

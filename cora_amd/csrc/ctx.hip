@@ -121,6 +121,10 @@ struct cora_ctx {
   bool fusedw2 = false;   // ... its two-workgroups-per-CU form (D = 128, heads of 32)
   bool frows_bwd1 = false;   // ... with the single-pass attention backward (N a multiple of 64, > 64)
   bool frows = false;     // D = 64 at any sequence length: row-tile fused kernels around attn.hip (fused_rows.hip)
+  // bf16 mode, per-op inference step: the two widest backward-data scratch tensors live as bf16 between their producer
+  // and the one GEMM that reads them (da: gelu' epilogue -> W1^T GEMM; dqkv: attention backward -> Wqkv^T GEMM).  The
+  // consumer rounds its A operand to bf16 anyway, so results are bit-identical; the learning pass keeps fp32.
+  bool da16 = false, dqkv16 = false;
   bool slotted() const { return fused || fusedw; }   // inference-step energies kept as 8 partial sums per vode (esum)
 
   // vodes
@@ -306,7 +310,7 @@ void run_gemm(cora_ctx* c, const GemmP& p_in, bool ako, bool bko) {
   }
   int kind = ako ? K_GEMM_TN : (bko ? K_GEMM_NN : K_GEMM_NT);
   double fl = 2.0 * p.R * (double)p.O * p.K * p.groups;
-  double by = 4.0 * p.groups * ((double)p.R * p.K + (double)p.O * p.K + (double)p.R * p.O);
+  double by = p.groups * ((p.a16 ? 2.0 : 4.0) * p.R * p.K + 4.0 * p.O * p.K + (p.c16 ? 2.0 : 4.0) * p.R * p.O);
   KScope s(c, kind, fl, by);
   launch_gemm(p, ako, bko, c->st);
 }
@@ -402,7 +406,8 @@ int block_forward(cora_ctx* c, int G, int b0, const float* xin, float* out, int 
 // and, when gout != null, the vode gradient g_l = scale_l (e_l + reg - dx) with its sum of squares.
 // raw: gout receives the cotangent dx itself (no gradient assembly) -- the vode LayerNorm stage finishes it.
 int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r, const float* own, float* gout, double* red,
-                   bool raw = false) {
+                   bool raw = false, bool half = false /* inference step: da / dqkv as bf16 where the ctx allows (da16, dqkv16) */) {
+  const bool da16 = half && c->da16, dq16 = half && c->dqkv16;
   const int D = c->D, M = c->M, H = c->H;
   const int R = (int)c->BN;
   const long long rows = (long long)G * R;
@@ -411,11 +416,11 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
   p.A = r; p.C = c->da;
   p.R = R; p.O = M; p.K = D; p.lda = D; p.ldc = M;
   p.sA = (long long)R * D; p.sB = (long long)D * M; p.sC = (long long)R * M;
-  p.mode = OUT_GELUGRAD; p.aux = c->a;
+  p.mode = OUT_GELUGRAD; p.aux = c->a; p.c16 = da16;
   run_gemm(c, p, false, bwd_weight(c, p, c->oW2 + (size_t)b0 * D * M, c->tW2 + (size_t)b0 * D * M));
   // dzn = da W1
   p = gemm_base(c, 1); p.groups = G;
-  p.A = c->da; p.C = c->dzn;
+  p.A = c->da; p.C = c->dzn; p.a16 = da16;
   p.R = R; p.O = D; p.K = M; p.lda = M; p.ldc = D;
   p.sA = (long long)R * M; p.sB = (long long)M * D; p.sC = (long long)R * D;
   run_gemm(c, p, false, bwd_weight(c, p, c->oW1 + (size_t)b0 * M * D, c->tW1 + (size_t)b0 * M * D));
@@ -436,12 +441,15 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
     double fl = 14.0 * G * c->B * (double)c->N * c->N * D;   // 7 products (S and dP are recomputed per side)
     KScope s(c, K_ATTN_BWD, fl, 4.0 * rows * 9 * D);
     if (c->cfg.dtype_mode == 1 && attn_bwd_bf16_supported(c->N, H, D)) {
-      if (launch_attn_bwd_bf16(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward (bf16): launch set-up failed");
-    } else if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+      if (launch_attn_bwd_bf16(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st, dq16)) FAIL(-3, "attention backward (bf16): launch set-up failed");
+    } else {
+      if (dq16) FAIL(-3, "attention backward: bf16 scratch without the bf16 kernels");
+      if (launch_attn_bwd(c->qkv, c->att, c->lse, c->dO, c->delta, c->dqkv, G * c->B, c->N, H, D, c->st)) FAIL(-3, "attention backward: head dim not supported");
+    }
   }
   // dxn = dqkv Wqkv
   p = gemm_base(c, 1); p.groups = G;
-  p.A = c->dqkv; p.C = c->dxn;
+  p.A = c->dqkv; p.C = c->dxn; p.a16 = dq16;
   p.R = R; p.O = D; p.K = 3 * D; p.lda = 3 * D; p.ldc = D;
   p.sA = (long long)R * 3 * D; p.sB = 3LL * D * D; p.sC = (long long)R * D;
   run_gemm(c, p, false, bwd_weight(c, p, c->oWqkv + (size_t)b0 * 3 * D * D, c->tWqkv + (size_t)b0 * 3 * D * D));
@@ -700,8 +708,8 @@ int infer_grad_step(cora_ctx* c, int t) {
   run_gemm(c, p, false, bko_out);
   if (L > 0) {
     if (c->frows) rc = block_backward_rows(c, ss + 8, 0);
-    else if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true);
-    else rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8);
+    else if (c->vln) rc = block_backward(c, L, 0, vode_in(c, 1), err_ptr(c, 2), nullptr, c->dxr, nullptr, true, true);
+    else rc = block_backward(c, L, 0, vode_ptr(c, c->Hs, 1), err_ptr(c, 2), err_ptr(c, 1), vode_ptr(c, c->Gs, 1), ss + 8, false, true);
     if (rc) return rc;
   }
   if (c->vln) {   // g_v = s_v (e_v + reg - LN_{v-1}^T dx'_v) for v = 1..L+1 in one grouped pass
@@ -1001,6 +1009,10 @@ int cora_create(const cora_config* cfg, int device, cora_ctx** out) {
         DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WTl = (unsigned short*)tmpb;
         DA(tmpb, (long long)(c->nWT + 1) / 2 + 4); c->WT3 = (unsigned short*)tmpb;
       }
+    }
+    if (cfg->dtype_mode == 1 && c->WTh && L > 0 && !getenv("CORA_NO_BWD16") && !getenv("CORA_BF16_NO_PRE") && !getenv("CORA_BF16_INREG")) {
+      c->da16 = (M % 8 == 0);
+      c->dqkv16 = ((3 * D) % 8 == 0) && attn_bwd_bf16_supported(c->N, c->H, c->D);
     }
     if (c->fused) DA(c->colpart, (long long)fused_colpart_floats(L, c->B));
     if (c->frows) DA(c->colpart, (long long)fused_rows_colpart_floats((int)L, c->BN));

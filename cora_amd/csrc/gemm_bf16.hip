@@ -37,6 +37,8 @@
 // deeper prefetch never materialises without hand-written waits).
 #include "common.h"
 #include "gemm_epilogue.h"
+#include <cstdio>
+#include <cstdlib>
 
 #ifndef EP_STREAM
 #define EP_STREAM true
@@ -88,7 +90,7 @@ __device__ __forceinline__ bf16x4 to_bf16_3(const float4 v, const bf16x4 h, cons
 #ifndef BF_OCC
 #define BF_OCC 2
 #endif
-template <int SPLIT, bool BPRE>
+template <int SPLIT, bool BPRE, bool A16 = false>
 __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
   __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
@@ -113,15 +115,30 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
 
   // staging: float4 #f of a 128 x TK tile = row f / KQ, k quad f % KQ; thread t takes #t + 256 i (row t / KQ + RSTEP i)
   const int srow = tid / KQ, skq = tid % KQ;
-  float4 ra[NV], rb[BPRE ? 1 : NVB];
-  uint4 pbh[NPB], pbl[NPB], pb3[NPB];
+  constexpr int NPA = TM * TK / 8 / 256;     // 16-byte pieces of a bf16 A tile per thread
+  float4 ra[A16 ? 1 : NV], rb[BPRE ? 1 : NVB];
+  uint4 pbh[NPB], pbl[NPB], pb3[NPB], pa16[A16 ? NPA : 1];
+  static_assert(!A16 || (SPLIT == 0 && BPRE && NTHR == 256 && TK == 32), "bf16 A operand: plain form, pre-converted B");
   auto load_tiles = [&](int k0) {
     const int gk = k0 + 4 * skq;
     const bool kok = gk < p.K;
+    if (A16) {
+      // A already bf16 in memory (backward-data scratch written as bf16 by its producer): 16-byte pieces of 8 bf16 go to
+      // LDS as they are, like the pre-converted weights -- half the bytes from HBM / L2 and no conversion work
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int gr = row0 + srow + RSTEP * i;
-      ra[i] = (kok && gr < p.R) ? *reinterpret_cast<const float4*>(A + (long long)gr * p.lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < NPA; ++i) {
+        const int f = tid + 256 * i;
+        const int gr = row0 + (f >> 2), gkb = k0 + 8 * (f & 3);
+        const bool ok = gkb < p.K && gr < p.R;
+        pa16[i] = ok ? *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + (long long)g * p.sA + (long long)gr * p.lda + gkb)
+                     : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int gr = row0 + srow + RSTEP * i;
+        ra[i] = (kok && gr < p.R) ? *reinterpret_cast<const float4*>(A + (long long)gr * p.lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if (BPRE) {
       // weights converted once per weight update (ctx.hip: refresh_wt): 16-byte pieces of 8 bf16 go to LDS as
@@ -146,8 +163,15 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel
     }
   };
   auto store_tiles = [&]() {
+    if (A16) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+      for (int i = 0; i < NPA; ++i) {
+        const int f = tid + 256 * i;
+        *reinterpret_cast<uint4*>(&Ah[(f >> 2) * LDR + 8 * (f & 3)]) = pa16[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (A16 ? 0 : NV); ++i) {
       float4 v = ra[i];
       const int o = (srow + RSTEP * i) * LDR + 4 * skq;
 #ifdef EXP_NOCVT   /* timing experiment (scripts/gemm_bf16_bench.hip): A as if pre-split by its producer -- no VALU between load and LDS */
@@ -294,6 +318,16 @@ void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st) {
   const bool pre = p.Bh != nullptr && (terms < 2 || p.Bl != nullptr) && (terms < 3 || p.B3 != nullptr) && p.K % 8 == 0 &&
                    p.ldb % 8 == 0 && p.sB % 8 == 0 && ((uintptr_t)p.Bh % 16) == 0 && (terms < 2 || ((uintptr_t)p.Bl % 16) == 0) &&
                    (terms < 3 || ((uintptr_t)p.B3 % 16) == 0);
+  if (p.a16 || p.c16) {
+    // set by ctx.hip only where these hold (checked at cora_create); anything else is a programming error
+    const bool ok16 = terms == 1 && pre && p.K % 8 == 0 && p.lda % 8 == 0 && p.sA % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && !p.a_gelu &&
+                      (!p.c16 || p.mode == OUT_GELUGRAD);
+    if (!ok16) { fprintf(stderr, "gemm_bf16: bf16 scratch operand requested for a GEMM that cannot take it\n"); abort(); }
+  }
+  if (p.a16) {
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, true, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
+    return;
+  }
   if (terms == 3) {
     if (pre) hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, true>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);
     else hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, false>), grid, dim3(NTHR), 0, st, p, tx, ty, ntiles);

@@ -82,7 +82,14 @@ __device__ __forceinline__ void gemm_ep_tile(const GemmP& p, const GemmEp& q, co
 #ifdef EXP_NOGELUGRAD   /* timing experiment: gelu'(a) as if left by the MLP1 epilogue */
       for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * t0[i]);
 #else
-      for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * cora_gelu_grad(t0[i]));
+      for (int i = 0; i < 16; ++i) if (EP_OK(i)) {
+        const float da = v[i] * cora_gelu_grad(t0[i]);
+        if (p.c16) {   // kept as bf16 for the next GEMM (GemmP::c16): the value that GEMM would round it to
+          __bf16* C16 = reinterpret_cast<__bf16*>(p.C) + (q.C - p.C);
+          const __bf16 b = (__bf16)da;
+          if (STREAM) __builtin_nontemporal_store(b, &C16[EP_IDX(i)]); else C16[EP_IDX(i)] = b;
+        } else EP_ST(&C[EP_IDX(i)], da);
+      }
 #endif
     } break;
     case OUT_GRAD: {

@@ -698,3 +698,36 @@ def test_graph_replay_matches_eager(monkeypatch):
         model.close()
     assert np.all(np.isfinite(traces[0])), traces[0]
     np.testing.assert_allclose(traces[0], traces[1], rtol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["cfg4_shape_B1", "n144_h2_headdim32", "n144_h1_headdim128"])
+def test_bf16_mode_backward_scratch_as_bf16_changes_no_bit(name, monkeypatch):
+    """bf16 mode, per-op inference step: da (gelu' epilogue -> W1^T GEMM) and dqkv (attention backward -> Wqkv^T GEMM) live
+    as bf16 between their producer and the one GEMM that reads them.  That GEMM rounds its A operand to bf16 anyway, so
+    vodes and their gradients must come out bit-identical to the fp32-scratch form (CORA_NO_BWD16=1); weight gradients
+    (learning pass: fp32 scratch in both) and energies agree to accumulation-order noise (split-K / slot atomics)."""
+    import cora_amd as ca
+    shape, p, D, H, L, B, T = CASES[name]
+
+    def run():
+        case = make_case(shape, p, D, H, L, B, seed=5)
+        model, optim_w, optim_h = build_model(case, compute_dtype="bf16")
+        assert model.kernel_path() == "per-op"
+        Eh, Ew, gh, gw, mse = ca.train_on_batch(T, case["x"], model=model, optim_w=optim_w, optim_h=optim_h)
+        tot, _ = ca.step_energies(model, T)
+        hs = [model.vodes[l].h.get() for l in range(L + 2)]
+        ghs = [np.asarray(gh[l]) for l in range(L + 2)]          # lazy device views: fetch before the ctx goes
+        gws = {k: np.asarray(gw[k]) for k in gw.keys()}
+        model.close()
+        return hs, ghs, gws, np.asarray(tot), mse
+
+    a = run()
+    monkeypatch.setenv("CORA_NO_BWD16", "1")
+    b = run()
+    for l in range(L + 2):
+        assert np.array_equal(a[0][l], b[0][l]), f"vode {l}"
+        assert np.array_equal(a[1][l], b[1][l]), f"final_h_grad {l}"
+    gmax = max(np.abs(v).max() for v in b[2].values())
+    for k in b[2]:
+        assert np.abs(a[2][k] - b[2][k]).max() <= 1e-6 * gmax, k
+    assert relerr(a[3], b[3]) <= 1e-9 and abs(a[4] - b[4]) <= 1e-6 * abs(b[4])     # MSE: after the (split-K) weight update
