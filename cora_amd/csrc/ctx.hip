@@ -429,7 +429,7 @@ int block_backward(cora_ctx* c, int G, int b0, const float* xin, const float* r,
     q.dxn = c->dzn; q.x = c->y; q.stats = c->st2; q.gamma = c->W + c->oLn2g + (size_t)b0 * D; q.sParam = D;
     q.r = r; q.out = c->dy; q.rows_per_group = R; q.groups = G; q.D = D; q.mode = 0;
     KScope s(c, K_LN_BWD, 0, 16.0 * rows * D);
-    if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: shape not supported (B*N % 4 != 0 or D too large)");
+    if (launch_ln_bwd(q, c->st)) FAIL(-3, "layer norm backward: hidden size not supported (D > 1024)");
   }
   // dO = dy Wo
   p = gemm_base(c, 1); p.groups = G;
