@@ -90,8 +90,12 @@ __device__ __forceinline__ bf16x4 to_bf16_3(const float4 v, const bf16x4 h, cons
 #ifndef BF_OCC
 #define BF_OCC 2
 #endif
+#ifndef BF_OCC_A16
+#define BF_OCC_A16 4   /* bf16 A operand: 8 staging registers instead of 16 -- four workgroups per CU at 128 registers (5 spilled):
+                         W1^T 124 -> 111 us, Wqkv^T 97 -> 88 us on the cfg 4 shapes; the fp32-A plain form spills 120 at that cap */
+#endif
 template <int SPLIT, bool BPRE, bool A16 = false>
-__global__ __launch_bounds__(NTHR, NTHR / 256 * BF_OCC) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
+__global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
   __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? TM * LDR : 8];
