@@ -325,7 +325,7 @@ void launch_gemm_bf16_nt(const GemmP& p, hipStream_t st) {
   if (p.a16 || p.c16) {
     // set by ctx.hip only where these hold (checked at cora_create); anything else is a programming error
     const bool ok16 = terms == 1 && pre && p.K % 8 == 0 && p.lda % 8 == 0 && p.sA % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && !p.a_gelu &&
-                      (!p.c16 || p.mode == OUT_GELUGRAD);
+                      (!p.c16 || (p.mode == OUT_GELUGRAD && p.O % 2 == 0 && p.ldc % 2 == 0 && p.sC % 2 == 0));
     if (!ok16) { fprintf(stderr, "gemm_bf16: bf16 scratch operand requested for a GEMM that cannot take it\n"); abort(); }
   }
   if (p.a16) {

@@ -78,17 +78,35 @@ __device__ __forceinline__ void gemm_ep_tile(const GemmP& p, const GemmEp& q, co
     } break;
     case OUT_GELUGRAD: {
       EP_FETCH(t0, q.aux);
-#pragma unroll
 #ifdef EXP_NOGELUGRAD   /* timing experiment: gelu'(a) as if left by the MLP1 epilogue */
+#pragma unroll
       for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * t0[i]);
 #else
-      for (int i = 0; i < 16; ++i) if (EP_OK(i)) {
-        const float da = v[i] * cora_gelu_grad(t0[i]);
-        if (p.c16) {   // kept as bf16 for the next GEMM (GemmP::c16): the value that GEMM would round it to
-          __bf16* C16 = reinterpret_cast<__bf16*>(p.C) + (q.C - p.C);
-          const __bf16 b = (__bf16)da;
-          if (STREAM) __builtin_nontemporal_store(b, &C16[EP_IDX(i)]); else C16[EP_IDX(i)] = b;
-        } else EP_ST(&C[EP_IDX(i)], da);
+      if (p.c16) {
+        // da kept as bf16 for the next GEMM (GemmP::c16): the value that GEMM would round it to.  Neighbouring lanes hold
+        // neighbouring columns: they pair up, the even lane stores rows 0..7 of both columns, the odd lane rows 8..15 --
+        // 8 four-byte stores per lane instead of 16 two-byte ones (W2^T GEMM of the cfg 4 shape: 333 -> 290 us).
+        // O and ldc are even (launcher), so a pair is inside or outside as a whole.
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        __bf16* C16 = reinterpret_cast<__bf16*>(p.C) + (q.C - p.C);
+        const bool odd = (col & 1) != 0;
+        const int cole = col & ~1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo = v[i] * cora_gelu_grad(t0[i]), hi = v[i + 8] * cora_gelu_grad(t0[i + 8]);
+          const float got = __shfl_xor(odd ? lo : hi, 1, 64);
+          const int ii = odd ? i + 8 : i;
+          bf2 pr;
+          pr[0] = (__bf16)(odd ? got : lo);      // even column
+          pr[1] = (__bf16)(odd ? hi : got);      // odd column
+          if (cole < p.O && EP_ROW(ii) < p.R) {
+            bf2* dst = reinterpret_cast<bf2*>(&C16[EP_ROW(ii) * p.ldc + cole]);
+            if (STREAM) __builtin_nontemporal_store(pr, dst); else *dst = pr;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (EP_OK(i)) EP_ST(&C[EP_IDX(i)], v[i] * cora_gelu_grad(t0[i]));
       }
 #endif
     } break;

@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
     p.groups = G; p.splitk = 1; p.alpha = 1.f; p.alpha2 = 1.f; p.mode = s.mode; p.a_gelu = s.a_gelu;
     p.red_stride = 1; p.bf16 = s.bf16;
     if (pre) { p.Bh = Bh; p.Bl = Bl; }
+    if (pre && argc > 2 && s.bf16 == 1 && s.mode == OUT_GELUGRAD) p.c16 = 1;   // ... and the gelu' epilogue writes bf16 (da)
     if (pre && argc > 2 && s.bf16 == 1 && s.mode == OUT_STORE) p.a16 = 1;   // second argument: plain GEMMs read A as bf16 (ctx.hip: da16 / dqkv16)
     if (s.mode == OUT_GELUGRAD) p.aux = X1;
     if (s.mode == OUT_ERR) { p.tgt = X1; p.red = red; }
