@@ -51,22 +51,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef BF_TK
 #define BF_TK 32
 #endif
+#ifndef BF_TK_A16
+#define BF_TK_A16 64
+#endif
 #ifndef BF_TM
 #define BF_TM 128
 #endif
 #ifndef BF_TN
 #define BF_TN 128
 #endif
-constexpr int TM = BF_TM, TN = BF_TN, TK = BF_TK;
+constexpr int TM = BF_TM, TN = BF_TN;     // the slab depth TK and what follows from it are set per kernel form (below)
 #ifndef BF_THREADS
 #define BF_THREADS 256
 #endif
 constexpr int NTHR = BF_THREADS, NWC = NTHR / 128;      // waves across the 128 columns (2 or 4); 2 wave rows of 64
 constexpr int WN = TN / NWC / 32;                        // 32-column MFMA tiles per wave (2 or 1)
 constexpr int WM = TM / 2 / 32;                          // 32-row MFMA tiles per wave (2 wave rows)
-constexpr int NVB = TN * TK / 4 / NTHR, NPB = TN * TK / 8 / NTHR;
-constexpr int KQ = TK / 4, NV = TM * TK / 4 / NTHR, RSTEP = NTHR / KQ;   // staging: float4 per row, per thread and operand, row step
-constexpr int LDR = TK + 8;          // bf16 per LDS row
 
 __device__ __forceinline__ bf16x4 to_bf16(const float4 v) {
   bf16x4 h;
@@ -91,11 +91,18 @@ __device__ __forceinline__ bf16x4 to_bf16_3(const float4 v, const bf16x4 h, cons
 #define BF_OCC 2
 #endif
 #ifndef BF_OCC_A16
-#define BF_OCC_A16 4   /* bf16 A operand: 8 staging registers instead of 16 -- four workgroups per CU at 128 registers (5 spilled):
-                         W1^T 124 -> 111 us, Wqkv^T 97 -> 88 us on the cfg 4 shapes; the fp32-A plain form spills 120 at that cap */
+#define BF_OCC_A16 3   /* bf16 A operand with 64-deep slabs: 163 registers, no spills (at 32-deep slabs it fits four workgroups per CU
+                         with 5 spilled registers: W1^T 111 us against 102 us for this form; 64-deep at four spills 141) */
 #endif
 template <int SPLIT, bool BPRE, bool A16 = false>
 __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) void gemm_bf16_nt_kernel(const GemmP p, const int tx, const int ty, const int ntiles) {
+  // slab depth: 32 for fp32 A operands (64 costs them a workgroup per CU); 64 for the bf16-A form, whose rows are then whole
+  // 128-byte lines per slab on both operands and whose staging still fits 163 registers (three workgroups per CU):
+  // W1^T 120 -> 102 us (866 TFLOP/s), Wqkv^T 89 -> 80 us on the cfg 4 shapes.
+  constexpr int TK = A16 ? BF_TK_A16 : BF_TK;
+  constexpr int NVB = TN * TK / 4 / NTHR, NPB = TN * TK / 8 / NTHR;
+  constexpr int KQ = TK / 4, NV = TM * TK / 4 / NTHR, RSTEP = NTHR / KQ;   // staging: float4 per row, per thread and operand, row step
+  constexpr int LDR = TK + 8;          // bf16 per LDS row
   __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * LDR];
   __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? TM * LDR : 8];
@@ -122,7 +129,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) voi
   constexpr int NPA = TM * TK / 8 / 256;     // 16-byte pieces of a bf16 A tile per thread
   float4 ra[A16 ? 1 : NV], rb[BPRE ? 1 : NVB];
   uint4 pbh[NPB], pbl[NPB], pb3[NPB], pa16[A16 ? NPA : 1];
-  static_assert(!A16 || (SPLIT == 0 && BPRE && NTHR == 256 && TK == 32), "bf16 A operand: plain form, pre-converted B");
+  static_assert(!A16 || (SPLIT == 0 && BPRE && NTHR == 256), "bf16 A operand: plain form, pre-converted B");
+  constexpr int PPR = TK / 8;                 // 16-byte pieces per tile row
   auto load_tiles = [&](int k0) {
     const int gk = k0 + 4 * skq;
     const bool kok = gk < p.K;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) voi
 #pragma unroll
       for (int i = 0; i < NPA; ++i) {
         const int f = tid + 256 * i;
-        const int gr = row0 + (f >> 2), gkb = k0 + 8 * (f & 3);
+        const int gr = row0 + f / PPR, gkb = k0 + 8 * (f % PPR);
         const bool ok = gkb < p.K && gr < p.R;
         pa16[i] = ok ? *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.A) + (long long)g * p.sA + (long long)gr * p.lda + gkb)
                      : make_uint4(0u, 0u, 0u, 0u);
@@ -147,11 +155,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) voi
     if (BPRE) {
       // weights converted once per weight update (ctx.hip: refresh_wt): 16-byte pieces of 8 bf16 go to LDS as
       // they are -- piece #f of the 128 x 32 tile = row f / 4, k octet f % 4; thread t takes #t and #t + 256
-      static_assert(!BPRE || (NTHR == 256 && TK == 32), "pre-converted B staging is written for 256 threads, 32-deep slabs");
+      static_assert(!BPRE || NTHR == 256, "pre-converted B staging is written for 256 threads");
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
         const int f = tid + 256 * i;
-        const int gc = col0 + (f >> 2), gkb = k0 + 8 * (f & 3);
+        const int gc = col0 + f / PPR, gkb = k0 + 8 * (f % PPR);
         const bool ok = gkb < p.K && gc < p.O;
         const long long off = (long long)g * p.sB + (long long)gc * p.ldb + gkb;
         pbh[i] = ok ? *reinterpret_cast<const uint4*>(p.Bh + off) : make_uint4(0u, 0u, 0u, 0u);
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) voi
 #pragma unroll
       for (int i = 0; i < NPA; ++i) {
         const int f = tid + 256 * i;
-        *reinterpret_cast<uint4*>(&Ah[(f >> 2) * LDR + 8 * (f & 3)]) = pa16[i];
+        *reinterpret_cast<uint4*>(&Ah[(f / PPR) * LDR + 8 * (f % PPR)]) = pa16[i];
       }
     }
 #pragma unroll
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 256 * (A16 ? BF_OCC_A16 : BF_OCC)) voi
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
         const int f = tid + 256 * i;
-        const int o = (f >> 2) * LDR + 8 * (f & 3);
+        const int o = (f / PPR) * LDR + 8 * (f % PPR);
         *reinterpret_cast<uint4*>(&Bh[o]) = pbh[i];
         if (SPLIT) *reinterpret_cast<uint4*>(&Bl[o]) = pbl[i];
         if (SPLIT == 2) *reinterpret_cast<uint4*>(&B3[o]) = pb3[i];
